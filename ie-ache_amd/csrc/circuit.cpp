@@ -1,0 +1,394 @@
+// See circuit.h.  Every builder function cites the cloud.c lines it mirrors.
+#include "circuit.h"
+
+#include <algorithm>
+#include <cassert>
+#include <stdexcept>
+
+namespace ieache {
+
+CircuitBuilder::CircuitBuilder(int32_t n_inputs)
+    : n_inputs_(n_inputs), next_wire_(n_inputs), wire_level_(n_inputs, 0) {}
+
+Ref CircuitBuilder::input(int32_t i) const {
+    if (i < 0 || i >= n_inputs_) throw std::out_of_range("circuit input index");
+    return Ref{i, false};
+}
+
+Word CircuitBuilder::input_word(int32_t first, int32_t count) const {
+    Word w(count);
+    for (int32_t i = 0; i < count; i++) w[i] = input(first + i);
+    return w;
+}
+
+Ref CircuitBuilder::gate(int32_t type, Ref a, Ref b) {
+    if (a.id == kUndefId || b.id == kUndefId)
+        throw std::logic_error("gate consumes a never-written sample");
+    const int32_t la = a.id >= 0 ? wire_level_[a.id] : 0;
+    const int32_t lb = b.id >= 0 ? wire_level_[b.id] : 0;
+    Gate g;
+    g.type = type;
+    g.a = a;
+    g.b = b;
+    g.out = next_wire_++;
+    g.level = std::max(la, lb) + 1;
+    wire_level_.push_back(g.level);
+    gates_.push_back(g);
+    return Ref{g.out, false};
+}
+
+// cloud.c:18-51.  carry-in is c[0] (bootsCOPY :24); carry-out lands in
+// carryover[0] only (:46).  sum may alias x (cloud.c:194): x[i] is read before
+// sum[i] is written, which SSA wires preserve by construction.
+void CircuitBuilder::add(Word& sum, Word& carryover, const Word& x, const Word& y, const Word& c,
+                         int32_t nb_bits) {
+    Ref carry = c[0];
+    for (int32_t i = 0; i < nb_bits; i++) {
+        const Ref xi = x[i], yi = y[i];
+        Ref axc = XOR(xi, carry);        // :30
+        const Ref bxc = XOR(yi, carry);  // :32
+        sum[i] = XOR(xi, bxc);           // :38
+        axc = AND(axc, bxc);             // :40
+        carry = XOR(carry, axc);         // :43
+    }
+    carryover[0] = carry;
+}
+
+void CircuitBuilder::zero(Word& result, size_t size) {  // cloud.c:53-57
+    for (size_t i = 0; i < size; i++) result[i] = constant(0);
+}
+
+void CircuitBuilder::NOT(Word& result, const Word& x, size_t size) {  // cloud.c:59-63
+    for (size_t i = 0; i < size; i++) result[i] = NOT(x[i]);
+}
+
+// cloud.c:65-113
+void CircuitBuilder::split(Word& f1, Word& f2, Word& f3, const Word& a, const Word& b, const Word& c,
+                           const Word& d, const Word& e, const Word& carry, int32_t nb_bits) {
+    Word sum = fresh(), sum2 = fresh(), sum3 = fresh();
+    Word co = fresh(), co2 = fresh(), co3 = fresh();
+    for (Word* w : {&sum, &sum2, &sum3, &co, &co2, &co3}) zero(*w, nb_bits);  // :77-87
+    add(sum, co, e, b, carry, nb_bits);                                          // :90
+    add(sum2, co2, d, a, co, nb_bits);                                           // :91
+    add(sum3, co3, c, co2, carry, nb_bits);  // :92  y = [carry-out, 0, 0, ...]
+    for (int32_t i = 0; i < nb_bits; i++) {  // :94-105
+        f1[i] = sum3[i];
+        f2[i] = sum2[i];
+        f3[i] = sum[i];
+    }
+}
+
+// Shift-add multiply of a `words`-word operand by one 32-bit word
+// (cloud.c:115-218, 220-385, 387-647).  Round r ANDs every operand bit with
+// multiplier bit r, places that row at bit offset r across words+1 words
+// (bits outside the row are bootsCONSTANT 0: cloud.c:164-192 and the
+// initial zeroing :132-145), then adds word by word with the carry chained
+// (:194-195, :355-357, :604-608).
+void CircuitBuilder::mul_words(std::vector<Word*> results, const std::vector<const Word*>& in,
+                               const Word& m, const Word& carry, int32_t nb_bits) {
+    const int words = (int)in.size(), W1 = words + 1;
+    assert((int)results.size() == W1 && nb_bits == 32);
+    std::vector<Word> sum(W1, Word(32, constant(0)));
+    std::vector<Word> cy(W1, Word(32, constant(0)));
+    for (int32_t r = 0; r < nb_bits; r++) {
+        // T[32w+k] = in[w][k] AND m[r]   (:150-162, :268-283, :452-473)
+        std::vector<Ref> T((size_t)32 * words);
+        for (int32_t kbit = 0; kbit < nb_bits; kbit++)
+            for (int w = 0; w < words; w++) T[32 * w + kbit] = AND((*in[w])[kbit], m[r]);
+        for (int w = 0; w < W1; w++) {
+            Word row(32);
+            for (int32_t q = 0; q < 32; q++) {
+                const int32_t pos = 32 * w + q - r;
+                row[q] = (pos >= 0 && pos < 32 * words) ? T[pos] : constant(0);
+            }
+            add(sum[w], cy[w], sum[w], row, w == 0 ? carry : cy[w - 1], 32);
+        }
+    }
+    for (int w = 0; w < W1; w++) *results[w] = sum[W1 - 1 - w];  // :200-204 high word first
+}
+
+void CircuitBuilder::mul32(Word& result, Word& result2, const Word& a, const Word& b,
+                           const Word& carry, int32_t nb_bits) {
+    mul_words({&result, &result2}, {&a}, b, carry, nb_bits);
+}
+void CircuitBuilder::mul64(Word& r, Word& r2, Word& r3, const Word& a, const Word& b, const Word& c,
+                           const Word& carry, int32_t nb_bits) {
+    mul_words({&r, &r2, &r3}, {&a, &b}, c, carry, nb_bits);
+}
+void CircuitBuilder::mul128(Word& r, Word& r2, Word& r3, Word& r4, Word& r5, const Word& a,
+                            const Word& b, const Word& c, const Word& d, const Word& e,
+                            const Word& carry, int32_t nb_bits) {
+    mul_words({&r, &r2, &r3, &r4, &r5}, {&a, &b, &c, &d}, e, carry, nb_bits);
+}
+
+Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const Word& outputs) {
+    Circuit c;
+    c.name = name;
+    c.n_inputs = b.n_inputs();
+    const auto& gates = b.gates();
+    const int32_t n_wires = b.n_wires();
+    int32_t depth = 0;
+    for (const Gate& g : gates) depth = std::max(depth, g.level);
+    c.depth = depth;
+    c.n_bootstraps = (int64_t)gates.size();
+
+    // order gates by level (stable: keeps the reference's program order inside a level)
+    std::vector<int32_t> order(gates.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t x, int32_t y) { return gates[x].level < gates[y].level; });
+    c.level_offset.assign(depth + 1, 0);
+    for (const Gate& g : gates) c.level_offset[g.level]++;
+    for (int32_t L = 1; L <= depth; L++) {
+        c.max_width = std::max(c.max_width, c.level_offset[L]);
+        c.level_offset[L] += c.level_offset[L - 1];
+    }
+
+    // liveness: last level at which each wire is read; outputs live forever
+    const int32_t kForever = depth + 1;
+    std::vector<int32_t> last_use(n_wires, 0);
+    for (const Gate& g : gates) {
+        if (g.a.id >= 0) last_use[g.a.id] = std::max(last_use[g.a.id], g.level);
+        if (g.b.id >= 0) last_use[g.b.id] = std::max(last_use[g.b.id], g.level);
+    }
+    for (const Ref& r : outputs) {
+        if (r.id == kUndefId) throw std::logic_error("circuit output was never written");
+        if (r.id >= 0) last_use[r.id] = kForever;
+    }
+    // slot allocation: inputs start in slots 0..n_inputs-1; a slot is recycled
+    // from the level AFTER its wire's last read, so no gate of a level ever
+    // overwrites a row another gate of the same level still reads.
+    std::vector<int32_t> slot_of(n_wires, -1);
+    std::vector<int32_t> free_slots;
+    std::vector<std::vector<int32_t>> dying(depth + 2);
+    int32_t n_slots = c.n_inputs;
+    for (int32_t w = 0; w < c.n_inputs; w++) {
+        slot_of[w] = w;
+        dying[last_use[w]].push_back(w);
+    }
+    for (int32_t w : dying[0]) free_slots.push_back(slot_of[w]);
+    c.gates.resize(gates.size());
+    size_t pos = 0;
+    for (int32_t L = 1; L <= depth; L++) {
+        const size_t end = (size_t)c.level_offset[L];
+        for (; pos < end; pos++) {
+            const Gate& g = gates[order[pos]];
+            int32_t s;
+            if (!free_slots.empty()) {
+                s = free_slots.back();
+                free_slots.pop_back();
+            } else {
+                s = n_slots++;
+            }
+            slot_of[g.out] = s;
+            dying[last_use[g.out] == 0 ? L : last_use[g.out]].push_back(g.out);  // unread wires die at once
+            DevGate& d = c.gates[pos];
+            d.type = g.type;
+            d.a_slot = g.a.id >= 0 ? slot_of[g.a.id] : -1;
+            d.a_neg = g.a.neg;
+            d.b_slot = g.b.id >= 0 ? slot_of[g.b.id] : -1;
+            d.b_neg = g.b.neg;
+            d.out_slot = s;
+            if (g.type == GATE_AND) c.n_and++;
+            if (g.type == GATE_XOR) c.n_xor++;
+        }
+        for (int32_t w : dying[L]) free_slots.push_back(slot_of[w]);
+    }
+    c.n_slots = n_slots;
+    c.outputs.resize(outputs.size());
+    for (size_t i = 0; i < outputs.size(); i++) {
+        c.outputs[i].slot = outputs[i].id >= 0 ? slot_of[outputs[i].id] : -1;
+        c.outputs[i].neg = outputs[i].neg;
+    }
+    return c;
+}
+
+int32_t circuit_n_inputs(int32_t kind, int32_t bits) {
+    switch (kind) {
+        case CIRC_ADD:
+        case CIRC_SUB:
+        case CIRC_RSUB:
+        case CIRC_MUL:
+            return 2 * bits + 32;
+        case CIRC_MULADD:
+            return 2 * bits + 32 + 2 * bits;
+    }
+    return -1;
+}
+
+int32_t circuit_n_outputs(int32_t kind, int32_t bits) {
+    switch (kind) {
+        case CIRC_ADD:
+        case CIRC_SUB:
+        case CIRC_RSUB:
+            return bits;
+        case CIRC_MUL:
+        case CIRC_MULADD:
+            return 2 * bits;
+    }
+    return -1;
+}
+
+// Split a flat bit vector into 32-bit words (the last may be shorter).
+static std::vector<Word> to_words(const Word& bits) {
+    std::vector<Word> w;
+    for (size_t i = 0; i < bits.size(); i += 32)
+        w.emplace_back(bits.begin() + i, bits.begin() + std::min(bits.size(), i + 32));
+    return w;
+}
+
+// W chained adds over word pairs (e.g. cloud.c:951-952, 1020-1023, 1109-1116)
+static Word chained_add(CircuitBuilder& b, const std::vector<Word>& x, const std::vector<Word>& y,
+                        const Word& carry_in) {
+    Word out;
+    Word prev = carry_in;
+    for (size_t w = 0; w < x.size(); w++) {
+        const int32_t nb = (int32_t)x[w].size();
+        Word res = CircuitBuilder::fresh(nb), cy = CircuitBuilder::fresh();
+        b.add(res, cy, x[w], y[w], prev, nb);
+        out.insert(out.end(), res.begin(), res.end());
+        prev = cy;
+    }
+    return out;
+}
+
+// two's complement of an operand, word by word (cloud.c:1225-1236, 1325-1341)
+static std::vector<Word> twos_complement(CircuitBuilder& b, const std::vector<Word>& v) {
+    std::vector<Word> twos;
+    Word temp = CircuitBuilder::fresh();
+    CircuitBuilder::zero(temp, 32);          // :1228
+    temp[0] = CircuitBuilder::constant(1);   // :1233
+    Word prev_carry;
+    for (size_t w = 0; w < v.size(); w++) {
+        const int32_t nb = (int32_t)v[w].size();
+        Word inverse = CircuitBuilder::fresh(nb), tempcarry = CircuitBuilder::fresh();
+        CircuitBuilder::NOT(inverse, v[w], nb);  // :1225
+        CircuitBuilder::zero(tempcarry, 32);     // :1229
+        Word res = CircuitBuilder::fresh(nb), cy = CircuitBuilder::fresh();
+        if (w == 0)
+            b.add(res, cy, inverse, temp, tempcarry, nb);  // :1236  +1
+        else
+            b.add(res, cy, inverse, tempcarry, prev_carry, nb);  // :1341 propagate
+        twos.push_back(res);
+        prev_carry = cy;
+    }
+    return twos;
+}
+
+bool build_circuit(int32_t kind, int32_t bits, Circuit* out) {
+    if (bits < 1 || bits > 256) return false;
+    const int32_t n_in = circuit_n_inputs(kind, bits);
+    if (n_in < 0) return false;
+    CircuitBuilder b(n_in);
+    Word A = b.input_word(0, bits), B = b.input_word(bits, bits);
+    const Word carry1 = b.input_word(2 * bits, 32);  // ciphertextcarry1
+    const std::vector<Word> Aw = to_words(A), Bw = to_words(B);
+    Word result;
+    std::string name;
+    switch (kind) {
+        case CIRC_ADD:
+            result = chained_add(b, Aw, Bw, carry1);
+            name = "add";
+            break;
+        case CIRC_SUB:  // cloud.c:1196-1807: complement operand 2, add to operand 1
+            result = chained_add(b, Aw, twos_complement(b, Bw), carry1);
+            name = "sub";
+            break;
+        case CIRC_RSUB:  // cloud.c:1809-2365: complement operand 1, add to operand 2
+            result = chained_add(b, Bw, twos_complement(b, Aw), carry1);
+            name = "rsub";
+            break;
+        case CIRC_MUL:
+        case CIRC_MULADD: {
+            if (kind == CIRC_MULADD && bits != 64) return false;
+            if (bits == 32) {  // cloud.c:2655-2718
+                Word r1 = b.fresh(), r2 = b.fresh();
+                b.mul32(r1, r2, Aw[0], Bw[0], carry1, 32);
+                result = r2;  // low word first (:2683-2686)
+                result.insert(result.end(), r1.begin(), r1.end());
+            } else if (bits == 64) {  // cloud.c:2568-2654
+                Word r[6], f[3];
+                for (auto& w : r) w = b.fresh();
+                for (auto& w : f) w = b.fresh();
+                b.mul64(r[0], r[1], r[2], Aw[0], Aw[1], Bw[0], carry1, 32);              // :2589
+                b.mul64(r[3], r[4], r[5], Aw[0], Aw[1], Bw[1], carry1, 32);              // :2592
+                b.split(f[0], f[1], f[2], r[0], r[1], r[3], r[4], r[5], carry1, 32);     // :2594
+                for (const Word* w : {&r[2], &f[2], &f[1], &f[0]})                       // :2609-2616
+                    result.insert(result.end(), w->begin(), w->end());
+            } else if (bits == 128) {  // cloud.c:2371-2567
+                Word r[21], sm[16], co[16];
+                for (auto& w : r) w = b.fresh();
+                for (auto& w : sm) w = b.fresh();
+                for (auto& w : co) w = b.fresh();
+                for (int q = 0; q < 4; q++)  // :2434-2443
+                    b.mul128(r[5 * q + 1], r[5 * q + 2], r[5 * q + 3], r[5 * q + 4], r[5 * q + 5],
+                             Aw[0], Aw[1], Aw[2], Aw[3], Bw[q], carry1, 32);
+                b.add(sm[1], co[1], r[10], r[4], carry1, 32);  // :2445-2449
+                b.add(sm[2], co[2], r[9], r[3], co[1], 32);
+                b.add(sm[3], co[3], r[8], r[2], co[2], 32);
+                b.add(sm[4], co[4], r[7], r[1], co[3], 32);
+                b.add(sm[5], co[5], r[6], carry1, co[4], 32);
+                b.add(sm[6], co[6], sm[2], r[15], co[5], 32);  // :2451-2455 (carry-in = previous chain's top carry)
+                b.add(sm[7], co[7], sm[3], r[14], co[6], 32);
+                b.add(sm[8], co[8], sm[4], r[13], co[7], 32);
+                b.add(sm[9], co[9], sm[5], r[12], co[8], 32);
+                b.add(sm[10], co[10], r[11], carry1, co[9], 32);
+                b.add(sm[11], co[11], sm[7], r[20], co[10], 32);  // :2457-2461
+                b.add(sm[12], co[12], sm[8], r[19], co[11], 32);
+                b.add(sm[13], co[13], sm[9], r[18], co[12], 32);
+                b.add(sm[14], co[14], sm[10], r[17], co[13], 32);
+                b.add(sm[15], co[15], r[16], carry1, co[14], 32);
+                for (const Word* w : {&r[5], &sm[1], &sm[6], &sm[11], &sm[12], &sm[13], &sm[14], &sm[15]})  // :2476-2491
+                    result.insert(result.end(), w->begin(), w->end());
+            } else {
+                return false;
+            }
+            name = "mul";
+            if (kind == CIRC_MULADD) {
+                // Second ./cloud run of compute_final() (dragonfly_cipher_cloud.py:1300-1327,
+                // flip == True: [answer | operand C]).  The stage-1 answer advertises
+                // 2*bits, so stage 2 is ADD at int_bit = 2*bits (cloud.c:841-855) over the
+                // answer's words and C's words, carry-in = the answer's carry word, which is
+                // operand A's carry word (cloud.c:2617-2626 fills it with ciphertextcarry1).
+                const Word C = b.input_word(2 * bits + 32, 2 * bits);
+                result = chained_add(b, to_words(result), to_words(C), carry1);
+                name = "muladd";
+            }
+            break;
+        }
+        default:
+            return false;
+    }
+    *out = finalize_circuit(name + std::to_string(bits), b, result);
+    return true;
+}
+
+void simulate_circuit(const Circuit& c, const uint8_t* in, uint8_t* out) {
+    std::vector<uint8_t> store(c.n_slots, 0);
+    for (int32_t i = 0; i < c.n_inputs; i++) store[i] = in[i] & 1;
+    auto val = [&](int32_t slot, int32_t neg) -> uint8_t {
+        const uint8_t v = slot >= 0 ? store[slot] : 0;
+        return v ^ (uint8_t)(neg & 1);
+    };
+    for (int32_t L = 1; L <= c.n_levels(); L++) {
+        // read every operand of the level before writing any output, as the GPU does
+        const int32_t lo = c.level_offset[L - 1], hi = c.level_offset[L];
+        std::vector<uint8_t> res(hi - lo);
+        for (int32_t g = lo; g < hi; g++) {
+            const DevGate& d = c.gates[g];
+            const uint8_t a = val(d.a_slot, d.a_neg), b = val(d.b_slot, d.b_neg);
+            uint8_t r = 0;
+            switch (d.type) {
+                case GATE_AND: r = a & b; break;
+                case GATE_XOR: r = a ^ b; break;
+                case GATE_OR: r = a | b; break;
+                case GATE_NAND: r = !(a & b); break;
+            }
+            res[g - lo] = r;
+        }
+        for (int32_t g = lo; g < hi; g++) store[c.gates[g].out_slot] = res[g - lo];
+    }
+    for (size_t i = 0; i < c.outputs.size(); i++) out[i] = val(c.outputs[i].slot, c.outputs[i].neg);
+}
+
+}  // namespace ieache

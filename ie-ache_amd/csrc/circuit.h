@@ -1,0 +1,135 @@
+// Gate-DAG form of the arithmetic circuits of /root/reference/Cloud/cloud.c.
+//
+// The reference evaluates its circuits one libtfhe gate at a time
+// (cloud.c:18-647).  Here the same gates are recorded as a DAG, levelised
+// ASAP (every gate of a level is independent) and given storage slots by
+// liveness so that a whole level -- times the batch of expressions -- is one
+// GPU launch.  bootsNOT / bootsCOPY / bootsCONSTANT cost no bootstrap in
+// libtfhe and none here: they are folded into wire references (sign flag,
+// alias, constant).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace ieache {
+
+// Reference to an LWE sample inside a circuit.
+//   id >= 0 : wire (inputs are wires 0..n_inputs-1, gate outputs follow)
+//   id == kConstId : bootsCONSTANT(0) = (0, -1/8); neg flips it to CONSTANT(1)
+//   id == kUndefId : never-written storage (new_gate_bootstrapping_ciphertext_array)
+struct Ref {
+    int32_t id;
+    bool neg;
+};
+constexpr int32_t kConstId = -1;
+constexpr int32_t kUndefId = -2;
+
+enum GateType : int32_t { GATE_AND = 0, GATE_XOR = 1, GATE_OR = 2, GATE_NAND = 3 };
+
+struct Gate {
+    int32_t type;
+    Ref a, b;
+    int32_t out;    // wire id
+    int32_t level;  // 1-based ASAP level
+};
+
+using Word = std::vector<Ref>;
+
+// Mirrors the helper functions of cloud.c on symbolic samples.
+class CircuitBuilder {
+public:
+    explicit CircuitBuilder(int32_t n_inputs);
+    Ref input(int32_t i) const;
+    Word input_word(int32_t first, int32_t count = 32) const;
+    static Ref constant(int v) { return Ref{kConstId, v != 0}; }            // bootsCONSTANT
+    static Ref NOT(Ref a) { return Ref{a.id, !a.neg}; }                     // bootsNOT
+    static Word fresh(int32_t count = 32) { return Word(count, Ref{kUndefId, false}); }
+    Ref gate(int32_t type, Ref a, Ref b);                                    // bootsAND / bootsXOR ...
+    Ref AND(Ref a, Ref b) { return gate(GATE_AND, a, b); }
+    Ref XOR(Ref a, Ref b) { return gate(GATE_XOR, a, b); }
+
+    // cloud.c:18-51
+    void add(Word& sum, Word& carryover, const Word& x, const Word& y, const Word& c, int32_t nb_bits);
+    // cloud.c:53-57 / 59-63
+    static void zero(Word& result, size_t size);
+    static void NOT(Word& result, const Word& x, size_t size);
+    // cloud.c:65-113
+    void split(Word& f1, Word& f2, Word& f3, const Word& a, const Word& b, const Word& c,
+               const Word& d, const Word& e, const Word& carry, int32_t nb_bits);
+    // cloud.c:115-218 / 220-385 / 387-647.  `in` low word first; `results` high word first.
+    void mul_words(std::vector<Word*> results, const std::vector<const Word*>& in, const Word& m,
+                   const Word& carry, int32_t nb_bits);
+    void mul32(Word& result, Word& result2, const Word& a, const Word& b, const Word& carry, int32_t nb_bits);
+    void mul64(Word& r, Word& r2, Word& r3, const Word& a, const Word& b, const Word& c,
+               const Word& carry, int32_t nb_bits);
+    void mul128(Word& r, Word& r2, Word& r3, Word& r4, Word& r5, const Word& a, const Word& b,
+                const Word& c, const Word& d, const Word& e, const Word& carry, int32_t nb_bits);
+
+    int32_t n_inputs() const { return n_inputs_; }
+    const std::vector<Gate>& gates() const { return gates_; }
+    int32_t n_wires() const { return next_wire_; }
+
+private:
+    int32_t n_inputs_;
+    int32_t next_wire_;
+    std::vector<Gate> gates_;
+    std::vector<int32_t> wire_level_;
+};
+
+// One gate as the device executor consumes it.  Slots index the wire store;
+// slot -1 means the constant (0,-1/8).  flags bit0 = negate the operand.
+struct DevGate {
+    int32_t type;
+    int32_t a_slot, a_neg;
+    int32_t b_slot, b_neg;
+    int32_t out_slot;
+};
+
+struct OutRef {
+    int32_t slot;  // -1 = constant
+    int32_t neg;
+};
+
+// A levelised, slot-allocated circuit, ready for the executor.
+struct Circuit {
+    std::string name;
+    int32_t n_inputs = 0;               // input samples per expression (slots 0..n_inputs-1 on entry)
+    int32_t n_slots = 0;                // wire-store rows per expression
+    std::vector<DevGate> gates;         // sorted by level
+    std::vector<int32_t> level_offset;  // gates of level L are [level_offset[L-1], level_offset[L])
+    std::vector<OutRef> outputs;        // output samples per expression
+    // statistics
+    int64_t n_bootstraps = 0, n_and = 0, n_xor = 0;
+    int32_t depth = 0, max_width = 0;
+    int32_t n_levels() const { return (int32_t)level_offset.size() - 1; }
+};
+
+// Levelise + allocate slots.  `outputs` are the samples to return per expression.
+Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const Word& outputs);
+
+// ---- the circuits main() dispatches to (cloud.c:870-2718) ----
+// Input sample order for all of them: operand 1 words (32 samples each, LSB
+// first, least-significant word first), operand 2 words, then operand 1's
+// carry word (ciphertextcarry1, 32 samples).  See `circuit_inputs()`.
+enum CircuitKind : int32_t {
+    CIRC_ADD = 1,     // A+B                  cloud.c:870-1190
+    CIRC_SUB = 2,     // A + (~B+1)           cloud.c:1196-1807
+    CIRC_RSUB = 3,    // B + (~A+1)           cloud.c:1809-2365
+    CIRC_MUL = 4,     // A*B, double width    cloud.c:2366-2718
+    CIRC_MULADD = 5,  // (A*B)+C fused two-stage (compute_final chaining), 64-bit A,B
+};
+
+// bits: operand width.  ADD/SUB/RSUB accept any bits >= 1 (the reference uses
+// 32/64/128/256; 16 is BASELINE.json's generalisation add(...,16,...));
+// MUL accepts 32/64/128.  Returns false for unsupported combinations.
+bool build_circuit(int32_t kind, int32_t bits, Circuit* out);
+// number of input / output samples per expression of a circuit kind
+int32_t circuit_n_inputs(int32_t kind, int32_t bits);
+int32_t circuit_n_outputs(int32_t kind, int32_t bits);
+
+// Pure-integer simulation of a circuit on plaintext bits (for host tests):
+// in[n_inputs] -> out[outputs.size()], each 0/1.
+void simulate_circuit(const Circuit& c, const uint8_t* in, uint8_t* out);
+
+}  // namespace ieache

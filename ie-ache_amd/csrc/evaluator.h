@@ -1,0 +1,84 @@
+// Device-side gate-bootstrapping evaluator (HIP, gfx950).
+//
+// Replaces, for whole levels of independent gates at once, what the reference
+// does one gate at a time through libtfhe's bootsAND / bootsXOR ->
+// tfhe_bootstrap_FFT (Cloud/cloud.c:30-43,159).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "circuit.h"
+#include "params.h"
+
+namespace ieache {
+
+struct EvalStats {
+    double total_ms = 0;         // wall time of the call on the GPU timeline (events on the stream)
+    double blind_rotate_ms = 0;  // sum over blind-rotation launches
+    double keyswitch_ms = 0;     // sum over key-switch launches
+    int64_t blind_rotate_launches = 0;
+    int64_t keyswitch_launches = 0;
+    int64_t bootstraps = 0;  // gate instances bootstrapped
+    int64_t levels = 0;
+};
+
+class Evaluator {
+public:
+    Evaluator(const Params& p, int device);
+    ~Evaluator();
+    Evaluator(const Evaluator&) = delete;
+    Evaluator& operator=(const Evaluator&) = delete;
+
+    const Params& params() const { return p_; }
+    int device() const { return device_; }
+    hipStream_t stream() const { return stream_; }
+
+    // Upload the cloud key.  Raw libtfhe order: bk [n][(k+1)l][k+1][N],
+    // ksk [kN][t][base][n+1].  The *_device form takes pointers already in this
+    // GPU's memory (e.g. the receive buffer of an RCCL broadcast).
+    void load_keys_host(const Torus32* bk, const Torus32* ksk);
+    void load_keys_device(const Torus32* d_bk, const Torus32* d_ksk);
+    bool keys_loaded() const { return keys_loaded_; }
+
+    // `count` independent gates of one type on device rows of lwe_stride()
+    // int32: out[i] = gate(a[i], b[i]).
+    void gates_device(int32_t type, size_t count, const Torus32* d_a, const Torus32* d_b,
+                      Torus32* d_out, EvalStats* stats);
+
+    // One circuit on `batch` independent expressions.
+    //   d_in  [batch][circuit.n_inputs][lwe_stride]
+    //   d_out [batch][circuit.outputs.size()][lwe_stride]
+    void eval_circuit_device(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
+                             EvalStats* stats);
+
+    // ---- single-stage hooks (parity tests compare each against its oracle stage) ----
+    // x [count][lwe_stride] -> acc [count][2][N] after `steps` CMux steps (steps<0: all n),
+    // starting from the test-vector initialisation.
+    void debug_blind_rotate(size_t count, const Torus32* d_x, Torus32* d_acc, int32_t steps);
+    // u [count][N+1] -> out [count][lwe_stride]
+    void debug_keyswitch(size_t count, const Torus32* d_u, Torus32* d_out);
+
+    // Force the generic (any-parameter) kernels even where a specialised one exists.
+    void set_force_generic(bool v) { force_generic_ = v; }
+    // Maximum gate instances per launch (bounds the scratch buffers).
+    void set_chunk(size_t items);
+    std::string kernel_variant() const;
+
+    struct Impl;  // device buffers; defined in evaluator.hip
+
+private:
+    Params p_;
+    int device_;
+    hipStream_t stream_ = nullptr;
+    bool keys_loaded_ = false;
+    bool force_generic_ = false;
+    Impl* d_ = nullptr;
+};
+
+// throws std::runtime_error carrying the HIP error string
+void hip_check(hipError_t e, const char* what, const char* file, int line);
+#define HIP_CHECK(x) ::ieache::hip_check((x), #x, __FILE__, __LINE__)
+
+}  // namespace ieache

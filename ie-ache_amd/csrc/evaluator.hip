@@ -1,0 +1,669 @@
+// Device evaluator: level-batched gate bootstrapping on MI355X (gfx950).
+//
+// Per gate instance (one bootsAND/bootsXOR of the reference, cloud.c:30-43,159):
+//   K0 gate pre-combination   t = cst + sa*ca + sb*cb          (boot-gates.cpp)
+//   K1 mod-switch             bara_i, barb in [0,2N)            (numeric-functions.cpp)
+//   K2 test-vector init       acc = (0, X^{2N-barb} * mu)       (lwe-bootstrapping-functions-fft.cpp)
+//   K3 blind rotation         n x  acc += BK_i (x) ((X^bara_i - 1) acc)
+//   K4 sample extract
+//   K5 key switch                                                 (lwe-keyswitch-functions.cpp)
+// K0-K4 are one kernel (k_blind_rotate_*), K5 is a second (k_keyswitch_*).
+//
+// The external product is EXACT.  libtfhe multiplies polynomials with an
+// approximate FP64 FFT; here every BK polynomial is split into two balanced
+// 16-bit limbs before the transform, so every inverse-transform output is an
+// integer of magnitude < 2^37 carried with > 15 spare mantissa bits and
+// rounding recovers it exactly.  Results therefore equal the integer
+// definition (and the CPU oracle) bit for bit, whatever the FFT schedule.
+#include "evaluator.h"
+
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+#include <vector>
+
+namespace ieache {
+
+void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e == hipSuccess) return;
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    throw std::runtime_error(buf);
+}
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct DevKeys {
+    int32_t n, N, M, logM, l, Bgbit, kpl, ks_t, ks_basebit, ks_base, stride;
+    uint32_t dec_offset;
+    const double2* bkf;   // [n][kpl][2][2 limbs][M], bit-reversed spectrum order
+    const int32_t* ksk;   // [N][t][base][stride]
+    const double2* twist; // exp(i*pi*j/N), j < M
+    const double2* wtab;  // exp(-2*pi*i*j/M), j < M/2
+};
+
+// Where the gate instances of one launch live.
+struct WorkDesc {
+    const DevGate* gates;  // circuit mode when non-null
+    int32_t g0, ng;
+    Torus32* store;
+    int32_t n_slots;
+    const Torus32* flat_a;  // flat mode: rows [item]
+    const Torus32* flat_b;
+    Torus32* flat_out;
+    int32_t flat_type;
+    int64_t item0;
+};
+
+struct GateInst {
+    const Torus32* a;
+    const Torus32* b;
+    Torus32* out;
+    int32_t sa, sb;  // signed multipliers (0 = operand is the constant, handled via cst)
+    uint32_t cst;
+};
+
+__device__ __forceinline__ void gate_coeffs(int32_t type, int32_t& k, uint32_t& cst) {
+    // boot-gates.cpp: AND (0,-1/8)+ca+cb ; XOR (0,1/4)+2(ca+cb) ; OR (0,1/8)+ca+cb ; NAND (0,1/8)-ca-cb
+    switch (type) {
+        case GATE_AND: k = 1; cst = 0xE0000000u; break;
+        case GATE_XOR: k = 2; cst = 0x40000000u; break;
+        case GATE_OR: k = 1; cst = 0x20000000u; break;
+        default: k = -1; cst = 0x20000000u; break;  // NAND
+    }
+}
+
+__device__ __forceinline__ GateInst resolve(const WorkDesc& W, int64_t item, int32_t stride) {
+    GateInst g;
+    int32_t type, k;
+    if (W.gates) {
+        const int64_t b = item / W.ng;
+        const DevGate d = W.gates[W.g0 + (int32_t)(item % W.ng)];
+        Torus32* base = W.store + (size_t)b * W.n_slots * stride;
+        type = d.type;
+        gate_coeffs(type, k, g.cst);
+        g.a = d.a_slot >= 0 ? base + (size_t)d.a_slot * stride : nullptr;
+        g.b = d.b_slot >= 0 ? base + (size_t)d.b_slot * stride : nullptr;
+        g.out = base + (size_t)d.out_slot * stride;
+        g.sa = d.a_neg ? -k : k;
+        g.sb = d.b_neg ? -k : k;
+        // a constant operand is (0, -1/8): only its b term contributes
+        if (!g.a) g.cst += (uint32_t)g.sa * 0xE0000000u;
+        if (!g.b) g.cst += (uint32_t)g.sb * 0xE0000000u;
+    } else {
+        type = W.flat_type;
+        gate_coeffs(type, k, g.cst);
+        g.a = W.flat_a + (size_t)item * stride;
+        g.b = W.flat_b ? W.flat_b + (size_t)item * stride : nullptr;
+        g.out = W.flat_out + (size_t)item * stride;
+        g.sa = k;
+        g.sb = k;
+        if (type < 0) {  // raw bootstrap of the row in flat_a (debug hook)
+            g.sa = 1;
+            g.sb = 0;
+            g.cst = 0;
+            g.b = nullptr;
+        }
+    }
+    return g;
+}
+
+__device__ __forceinline__ uint32_t combined_coef(const GateInst& g, int32_t i, int32_t n) {
+    uint32_t v = 0;
+    if (g.a) v += (uint32_t)g.sa * (uint32_t)g.a[i];
+    if (g.b) v += (uint32_t)g.sb * (uint32_t)g.b[i];
+    if (i == n) v += g.cst;
+    return v;
+}
+
+// libtfhe modSwitchFromTorus32(phase, 2N) for power-of-two N: (phase + 2^(31-log2(2N))) >> (32-log2(2N))
+__device__ __forceinline__ int32_t modswitch2N(uint32_t phase, int32_t log2N2) {
+    return (int32_t)((phase + (1u << (31 - log2N2))) >> (32 - log2N2));
+}
+
+// coefficient i of X^a * p  (mod X^N+1), a in [0,2N)
+__device__ __forceinline__ int32_t rot_coef(const int32_t* p, int32_t i, int32_t a, int32_t N) {
+    const int32_t idx = (i - a) & (2 * N - 1);
+    return idx < N ? p[idx] : (int32_t)(0u - (uint32_t)p[idx - N]);
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmul_conj(double2 a, double2 b) {  // a * conj(b)
+    return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ double2 cfma(double2 a, double2 b, double2 c) {  // a*b + c
+    return make_double2(fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y)));
+}
+
+// In-LDS radix-2 transforms over `npoly` polynomials of M complex points.
+// Forward: DIF, natural in -> bit-reversed out.  Inverse: DIT, bit-reversed in
+// -> natural out, unscaled.  Neither needs a permutation pass.
+__device__ void fft_forward_lds(double2* F, int32_t npoly, int32_t M, int32_t logM, const double2* wtab) {
+    const int32_t halfM = M >> 1, total = npoly * halfM;
+    for (int32_t sh = 0; sh < logM; sh++) {
+        const int32_t half = halfM >> sh;
+        for (int32_t t = threadIdx.x; t < total; t += blockDim.x) {
+            const int32_t poly = t / halfM, bf = t - poly * halfM;
+            const int32_t j = bf & (half - 1), grp = bf >> (logM - 1 - sh);
+            const int32_t a = poly * M + (grp * 2 * half) + j, b = a + half;
+            const double2 w = wtab[j << sh];
+            const double2 u = F[a], v = F[b];
+            F[a] = make_double2(u.x + v.x, u.y + v.y);
+            F[b] = cmul(make_double2(u.x - v.x, u.y - v.y), w);
+        }
+        __syncthreads();
+    }
+}
+__device__ void fft_inverse_lds(double2* F, int32_t npoly, int32_t M, int32_t logM, const double2* wtab) {
+    const int32_t halfM = M >> 1, total = npoly * halfM;
+    for (int32_t st = 0; st < logM; st++) {
+        const int32_t half = 1 << st, sh = logM - 1 - st;
+        for (int32_t t = threadIdx.x; t < total; t += blockDim.x) {
+            const int32_t poly = t / halfM, bf = t - poly * halfM;
+            const int32_t j = bf & (half - 1), grp = bf >> st;
+            const int32_t a = poly * M + (grp * 2 * half) + j, b = a + half;
+            const double2 w = wtab[j << sh];
+            const double2 u = F[a], v = cmul_conj(F[b], w);
+            F[a] = make_double2(u.x + v.x, u.y + v.y);
+            F[b] = make_double2(u.x - v.x, u.y - v.y);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- key preparation: BK polynomial -> two-limb spectrum ----
+__global__ __launch_bounds__(kThreads) void k_bk_to_spectrum(DevKeys K, const Torus32* bk_raw, double2* bkf) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* F = reinterpret_cast<double2*>(smem);  // [2][M]
+    const int32_t M = K.M;
+    const Torus32* src = bk_raw + (size_t)blockIdx.x * K.N;
+    for (int32_t j = threadIdx.x; j < M; j += blockDim.x) {
+        const int32_t v0 = src[j], v1 = src[j + M];
+        const int32_t lo0 = (int16_t)(v0 & 0xFFFF), lo1 = (int16_t)(v1 & 0xFFFF);
+        const int32_t hi0 = (int32_t)(((int64_t)v0 - lo0) >> 16), hi1 = (int32_t)(((int64_t)v1 - lo1) >> 16);
+        const double2 tw = K.twist[j];
+        F[j] = cmul(make_double2((double)lo0, (double)lo1), tw);
+        F[M + j] = cmul(make_double2((double)hi0, (double)hi1), tw);
+    }
+    __syncthreads();
+    fft_forward_lds(F, 2, M, K.logM, K.wtab);
+    double2* dst = bkf + (size_t)blockIdx.x * 2 * M;
+    for (int32_t j = threadIdx.x; j < 2 * M; j += blockDim.x) dst[j] = F[j];
+}
+
+// raw KSK rows (n+1) -> padded rows (stride)
+__global__ void k_pad_rows(const Torus32* src, Torus32* dst, int64_t rows, int32_t width, int32_t stride) {
+    const int64_t total = rows * stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / stride;
+        const int32_t c = (int32_t)(i - r * stride);
+        dst[i] = c < width ? src[r * width + c] : 0;
+    }
+}
+
+// ---- K0..K4, generic parameters: one workgroup per gate instance ----
+// LDS: F [max(kpl,4)][M] double2 | acc [2][N] int32 | bara [n] u16
+__global__ __launch_bounds__(kThreads) void k_blind_rotate_generic(DevKeys K, WorkDesc W, Torus32* ext,
+                                                                   int32_t steps, Torus32* dbg_acc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int32_t N = K.N, M = K.M, n = K.n, l = K.l, kpl = K.kpl;
+    const int32_t frows = kpl > 4 ? kpl : 4;
+    double2* F = reinterpret_cast<double2*>(smem);
+    int32_t* acc = reinterpret_cast<int32_t*>(F + (size_t)frows * M);
+    uint16_t* bara = reinterpret_cast<uint16_t*>(acc + 2 * N);
+    __shared__ int32_t s_barb;
+
+    const int64_t item = (int64_t)blockIdx.x;
+    const GateInst g = resolve(W, W.item0 + item, K.stride);
+    const int32_t log2N2 = K.logM + 2;
+
+    // K0 + K1
+    for (int32_t i = threadIdx.x; i <= n; i += blockDim.x) {
+        const int32_t bar = modswitch2N(combined_coef(g, i, n), log2N2);
+        if (i < n)
+            bara[i] = (uint16_t)bar;
+        else
+            s_barb = bar;
+    }
+    __syncthreads();
+    // K2: acc = (0, X^{2N-barb} * (mu,...,mu))
+    {
+        const int32_t a0 = (2 * N - s_barb) & (2 * N - 1);
+        for (int32_t j = threadIdx.x; j < N; j += blockDim.x) {
+            acc[j] = 0;
+            const int32_t idx = (j - a0) & (2 * N - 1);
+            acc[N + j] = idx < N ? kMU : -kMU;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t halfBg = 1u << (K.Bgbit - 1), maskBg = (1u << K.Bgbit) - 1;
+    const double invM = 1.0 / (double)M;
+    const int32_t nsteps = steps < 0 ? n : steps;
+    // K3
+    for (int32_t i = 0; i < nsteps; i++) {
+        const int32_t a = bara[i];
+        if (a == 0) continue;  // uniform across the workgroup; exact arithmetic makes the step a no-op
+        // (X^a - 1) * acc, gadget decomposition, fold + twist
+        for (int32_t j = threadIdx.x; j < M; j += blockDim.x) {
+            const double2 tw = K.twist[j];
+#pragma unroll 2
+            for (int32_t c = 0; c < 2; c++) {
+                const int32_t* p = acc + c * N;
+                const uint32_t d0 = (uint32_t)rot_coef(p, j, a, N) - (uint32_t)p[j] + K.dec_offset;
+                const uint32_t d1 = (uint32_t)rot_coef(p, j + M, a, N) - (uint32_t)p[j + M] + K.dec_offset;
+                for (int32_t q = 0; q < l; q++) {
+                    const int32_t sh = 32 - (q + 1) * K.Bgbit;
+                    const int32_t e0 = (int32_t)((d0 >> sh) & maskBg) - (int32_t)halfBg;
+                    const int32_t e1 = (int32_t)((d1 >> sh) & maskBg) - (int32_t)halfBg;
+                    F[(size_t)(c * l + q) * M + j] = cmul(make_double2((double)e0, (double)e1), tw);
+                }
+            }
+        }
+        __syncthreads();
+        fft_forward_lds(F, kpl, M, K.logM, K.wtab);
+        // spectrum-domain accumulate: out(c,limb) = sum_row dec[row] * BK_i[row][c][limb]
+        const double2* bki = K.bkf + (size_t)i * kpl * 4 * M;
+        for (int32_t pt = threadIdx.x; pt < M; pt += blockDim.x) {
+            double2 s[4];
+#pragma unroll
+            for (int32_t q = 0; q < 4; q++) s[q] = make_double2(0.0, 0.0);
+            for (int32_t row = 0; row < kpl; row++) {
+                const double2 d = F[(size_t)row * M + pt];
+                const double2* b = bki + (size_t)row * 4 * M + pt;
+#pragma unroll
+                for (int32_t q = 0; q < 4; q++) s[q] = cfma(d, b[(size_t)q * M], s[q]);
+            }
+            // every thread has consumed its own column of F; rows 0..3 become the outputs
+#pragma unroll
+            for (int32_t q = 0; q < 4; q++) F[(size_t)q * M + pt] = s[q];
+        }
+        __syncthreads();
+        fft_inverse_lds(F, 4, M, K.logM, K.wtab);
+        // untwist, round, recombine limbs, accumulate
+        for (int32_t j = threadIdx.x; j < M; j += blockDim.x) {
+            const double2 tw = K.twist[j];
+#pragma unroll 2
+            for (int32_t c = 0; c < 2; c++) {
+                const double2 lo = cmul_conj(F[(size_t)(2 * c) * M + j], tw);
+                const double2 hi = cmul_conj(F[(size_t)(2 * c + 1) * M + j], tw);
+                const int64_t r0 = __double2ll_rn(lo.x * invM) + (__double2ll_rn(hi.x * invM) << 16);
+                const int64_t r1 = __double2ll_rn(lo.y * invM) + (__double2ll_rn(hi.y * invM) << 16);
+                acc[c * N + j] = (int32_t)((uint32_t)acc[c * N + j] + (uint32_t)r0);
+                acc[c * N + j + M] = (int32_t)((uint32_t)acc[c * N + j + M] + (uint32_t)r1);
+            }
+        }
+        __syncthreads();
+    }
+    if (dbg_acc) {
+        for (int32_t j = threadIdx.x; j < 2 * N; j += blockDim.x) dbg_acc[(size_t)item * 2 * N + j] = acc[j];
+    }
+    // K4: u = (a'_0 = acc.a_0, a'_j = -acc.a_{N-j}; b' = acc.b_0)
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (N + 4);
+        for (int32_t j = threadIdx.x; j <= N; j += blockDim.x)
+            u[j] = j == 0 ? acc[0] : (j == N ? acc[N] : (int32_t)(0u - (uint32_t)acc[N - j]));
+    }
+}
+
+// ---- K5, generic: one workgroup per gate instance ----
+// LDS: u [N+1] | list [N*t] | count
+__global__ __launch_bounds__(kThreads) void k_keyswitch_generic(DevKeys K, WorkDesc W, const Torus32* ext,
+                                                                Torus32* flat_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int32_t N = K.N, n = K.n, t = K.ks_t, basebit = K.ks_basebit, stride = K.stride;
+    int32_t* u = reinterpret_cast<int32_t*>(smem);
+    uint32_t* list = reinterpret_cast<uint32_t*>(u + N + 4);
+    __shared__ uint32_t s_count;
+    const int64_t item = (int64_t)blockIdx.x;
+    const Torus32* src = ext + (size_t)item * (N + 4);
+    if (threadIdx.x == 0) s_count = 0;
+    for (int32_t j = threadIdx.x; j <= N; j += blockDim.x) u[j] = src[j];
+    __syncthreads();
+    const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+    const uint32_t mask = (1u << basebit) - 1;
+    for (int32_t idx = threadIdx.x; idx < N * t; idx += blockDim.x) {
+        const int32_t i = idx / t, j = idx - i * t;
+        const uint32_t d = (((uint32_t)u[i] + prec_offset) >> (32 - (j + 1) * basebit)) & mask;
+        if (d) list[atomicAdd(&s_count, 1u)] = ((uint32_t)idx << basebit) + d;  // row index [i][j][d]
+    }
+    __syncthreads();
+    const uint32_t cnt = s_count;
+    // subtraction mod 2^32 commutes, so the (non-deterministic) list order does not matter
+    uint32_t r0 = 0, r1 = 0, r2 = 0;
+    const int32_t q0 = threadIdx.x, q1 = q0 + kThreads, q2 = q0 + 2 * kThreads;
+    for (uint32_t e = 0; e < cnt; e++) {
+        const int32_t* row = K.ksk + (size_t)list[e] * stride;
+        if (q0 < stride) r0 -= (uint32_t)row[q0];
+        if (q1 < stride) r1 -= (uint32_t)row[q1];
+        if (q2 < stride) r2 -= (uint32_t)row[q2];
+    }
+    Torus32* out = flat_out ? flat_out + (size_t)item * stride : resolve(W, W.item0 + item, stride).out;
+    const uint32_t bprime = (uint32_t)u[N];
+    if (q0 <= n) out[q0] = (int32_t)(r0 + (q0 == n ? bprime : 0u));
+    else if (q0 < stride) out[q0] = 0;
+    if (q1 < stride) out[q1] = q1 <= n ? (int32_t)(r1 + (q1 == n ? bprime : 0u)) : 0;
+    if (q2 < stride) out[q2] = q2 <= n ? (int32_t)(r2 + (q2 == n ? bprime : 0u)) : 0;
+}
+
+// outputs of a circuit: out[b][o] = +-store[b][slot] or the constant
+__global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus32* store, int32_t n_slots,
+                                 Torus32* out, int64_t batch, int32_t stride, int32_t n) {
+    const int64_t row = blockIdx.x;  // b * n_out + o
+    const int64_t b = row / n_out;
+    const OutRef r = outs[row % n_out];
+    Torus32* dst = out + (size_t)row * stride;
+    for (int32_t q = threadIdx.x; q < stride; q += blockDim.x) {
+        uint32_t v;
+        if (r.slot >= 0)
+            v = (uint32_t)store[((size_t)b * n_slots + r.slot) * stride + q];
+        else
+            v = q == n ? 0xE0000000u : 0u;
+        if (r.neg) v = 0u - v;
+        dst[q] = q <= n ? (int32_t)v : 0;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------
+struct Evaluator::Impl {
+    DevKeys K{};
+    double2* bkf = nullptr;
+    int32_t* ksk = nullptr;
+    double2* twist = nullptr;
+    double2* wtab = nullptr;
+    Torus32* ext = nullptr;
+    size_t chunk = 16384;
+    size_t ext_items = 0;
+    Torus32* store = nullptr;
+    size_t store_bytes = 0;
+    DevGate* d_gates = nullptr;
+    size_t d_gates_cap = 0;
+    OutRef* d_outs = nullptr;
+    size_t d_outs_cap = 0;
+    size_t br_lds = 0, ks_lds = 0;
+};
+
+Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(new Impl) {
+    if (!p.supported()) throw std::invalid_argument("unsupported TFHE parameter set");
+    int count = 0;
+    HIP_CHECK(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) throw std::runtime_error("no such HIP device");
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    DevKeys& K = d_->K;
+    K.n = p.n;
+    K.N = p.N;
+    K.M = p.N / 2;
+    K.logM = 0;
+    while ((1 << K.logM) < K.M) K.logM++;
+    K.l = p.l;
+    K.Bgbit = p.Bgbit;
+    K.kpl = p.kpl();
+    K.ks_t = p.ks_t;
+    K.ks_basebit = p.ks_basebit;
+    K.ks_base = p.ks_base();
+    K.stride = p.lwe_stride();
+    K.dec_offset = 0;
+    for (int32_t i = 1; i <= p.l; i++) K.dec_offset += (1u << (p.Bgbit - 1)) << (32 - i * p.Bgbit);
+    // twiddles, computed once in double precision on the host
+    const int32_t M = K.M;
+    std::vector<double2> tw(M), w(M / 2 > 0 ? M / 2 : 1);
+    for (int32_t j = 0; j < M; j++) tw[j] = make_double2(std::cos(M_PI * j / p.N), std::sin(M_PI * j / p.N));
+    for (int32_t j = 0; j < M / 2; j++)
+        w[j] = make_double2(std::cos(-2.0 * M_PI * j / M), std::sin(-2.0 * M_PI * j / M));
+    HIP_CHECK(hipMalloc(&d_->twist, sizeof(double2) * tw.size()));
+    HIP_CHECK(hipMalloc(&d_->wtab, sizeof(double2) * w.size()));
+    HIP_CHECK(hipMemcpy(d_->twist, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_->wtab, w.data(), sizeof(double2) * w.size(), hipMemcpyHostToDevice));
+    K.twist = d_->twist;
+    K.wtab = d_->wtab;
+    const int32_t frows = K.kpl > 4 ? K.kpl : 4;
+    d_->br_lds = (size_t)frows * M * sizeof(double2) + (size_t)2 * p.N * 4 + (((size_t)p.n * 2 + 15) & ~(size_t)15);
+    d_->ks_lds = (size_t)(p.N + 4) * 4 + (size_t)p.N * p.ks_t * 4;
+    if (d_->br_lds > 160 * 1024 || d_->ks_lds > 160 * 1024)
+        throw std::invalid_argument("parameter set exceeds the 160 KiB LDS of a CU");
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_blind_rotate_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d_->br_lds));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_keyswitch_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d_->ks_lds));
+}
+
+Evaluator::~Evaluator() {
+    if (!d_) return;
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    (void)hipFree(d_->bkf);
+    (void)hipFree(d_->ksk);
+    (void)hipFree(d_->twist);
+    (void)hipFree(d_->wtab);
+    (void)hipFree(d_->ext);
+    (void)hipFree(d_->store);
+    (void)hipFree(d_->d_gates);
+    (void)hipFree(d_->d_outs);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    delete d_;
+}
+
+void Evaluator::set_chunk(size_t items) {
+    if (items < 1) items = 1;
+    d_->chunk = items;
+}
+
+std::string Evaluator::kernel_variant() const { return "generic-radix2"; }
+
+void Evaluator::load_keys_host(const Torus32* bk, const Torus32* ksk) {
+    HIP_CHECK(hipSetDevice(device_));
+    Torus32 *d_bk = nullptr, *d_ksk = nullptr;
+    HIP_CHECK(hipMalloc(&d_bk, p_.bk_count() * 4));
+    HIP_CHECK(hipMalloc(&d_ksk, p_.ksk_count() * 4));
+    HIP_CHECK(hipMemcpy(d_bk, bk, p_.bk_count() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_ksk, ksk, p_.ksk_count() * 4, hipMemcpyHostToDevice));
+    try {
+        load_keys_device(d_bk, d_ksk);
+    } catch (...) {
+        (void)hipFree(d_bk);
+        (void)hipFree(d_ksk);
+        throw;
+    }
+    HIP_CHECK(hipFree(d_bk));
+    HIP_CHECK(hipFree(d_ksk));
+}
+
+void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
+    HIP_CHECK(hipSetDevice(device_));
+    DevKeys& K = d_->K;
+    const size_t npoly = (size_t)p_.n * K.kpl * 2;
+    if (!d_->bkf) HIP_CHECK(hipMalloc(&d_->bkf, npoly * 2 * K.M * sizeof(double2)));
+    const size_t ks_rows = (size_t)p_.k * p_.N * p_.ks_t * K.ks_base;
+    if (!d_->ksk) HIP_CHECK(hipMalloc(&d_->ksk, ks_rows * K.stride * 4));
+    K.bkf = d_->bkf;
+    K.ksk = d_->ksk;
+    hipLaunchKernelGGL(k_bk_to_spectrum, dim3((unsigned)npoly), dim3(kThreads), 2 * K.M * sizeof(double2), stream_, K,
+                       d_bk, d_->bkf);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_pad_rows, dim3(2048), dim3(256), 0, stream_, d_ksk, d_->ksk, (int64_t)ks_rows, p_.n + 1,
+                       K.stride);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    keys_loaded_ = true;
+}
+
+namespace {
+struct Timer {
+    std::vector<hipEvent_t> ev;  // pairs
+    bool on;
+    hipStream_t s;
+    Timer(bool enabled, hipStream_t st) : on(enabled), s(st) {}
+    ~Timer() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+    void mark() {
+        if (!on) return;
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(e, s));
+        ev.push_back(e);
+    }
+    double sum_ms() {
+        double tot = 0;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            tot += ms;
+        }
+        return tot;
+    }
+};
+}  // namespace
+
+// Runs `items` gate instances described by W (item0 is advanced per chunk).
+static void run_items(Evaluator::Impl* d, hipStream_t stream, WorkDesc W, int64_t items,
+                      Timer& tbr, Timer& tks, EvalStats* stats) {
+    const DevKeys& K = d->K;
+    const size_t chunk = d->chunk;
+    if (d->ext_items < chunk) {
+        if (d->ext) HIP_CHECK(hipFree(d->ext));
+        HIP_CHECK(hipMalloc(&d->ext, chunk * (size_t)(K.N + 4) * 4));
+        d->ext_items = chunk;
+    }
+    for (int64_t done = 0; done < items; done += (int64_t)chunk) {
+        const int64_t cnt = std::min<int64_t>((int64_t)chunk, items - done);
+        WorkDesc w = W;
+        w.item0 = W.item0 + done;
+        tbr.mark();
+        hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, K, w, d->ext,
+                           -1, (Torus32*)nullptr);
+        tbr.mark();
+        HIP_CHECK(hipGetLastError());
+        tks.mark();
+        hipLaunchKernelGGL(k_keyswitch_generic, dim3((unsigned)cnt), dim3(kThreads), d->ks_lds, stream, K, w, d->ext,
+                           (Torus32*)nullptr);
+        tks.mark();
+        HIP_CHECK(hipGetLastError());
+        if (stats) {
+            stats->blind_rotate_launches++;
+            stats->keyswitch_launches++;
+        }
+    }
+    if (stats) stats->bootstraps += items;
+}
+
+void Evaluator::gates_device(int32_t type, size_t count, const Torus32* d_a, const Torus32* d_b, Torus32* d_out,
+                             EvalStats* stats) {
+    if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
+    HIP_CHECK(hipSetDevice(device_));
+    if (count == 0) return;
+    Timer tall(stats != nullptr, stream_), tbr(stats != nullptr, stream_), tks(stats != nullptr, stream_);
+    WorkDesc W{};
+    W.gates = nullptr;
+    W.flat_a = d_a;
+    W.flat_b = d_b;
+    W.flat_out = d_out;
+    W.flat_type = type;
+    W.item0 = 0;
+    tall.mark();
+    run_items(d_, stream_, W, (int64_t)count, tbr, tks, stats);
+    tall.mark();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (stats) {
+        stats->total_ms += tall.sum_ms();
+        stats->blind_rotate_ms += tbr.sum_ms();
+        stats->keyswitch_ms += tks.sum_ms();
+        stats->levels += 1;
+    }
+}
+
+void Evaluator::eval_circuit_device(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
+                                    EvalStats* stats) {
+    if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
+    HIP_CHECK(hipSetDevice(device_));
+    if (batch == 0) return;
+    const int32_t stride = d_->K.stride;
+    const size_t row_bytes = (size_t)stride * 4;
+    const size_t need = batch * (size_t)c.n_slots * row_bytes;
+    if (d_->store_bytes < need) {
+        if (d_->store) HIP_CHECK(hipFree(d_->store));
+        d_->store = nullptr;
+        d_->store_bytes = 0;
+        HIP_CHECK(hipMalloc(&d_->store, need));
+        d_->store_bytes = need;
+    }
+    if (d_->d_gates_cap < c.gates.size()) {
+        if (d_->d_gates) HIP_CHECK(hipFree(d_->d_gates));
+        HIP_CHECK(hipMalloc(&d_->d_gates, c.gates.size() * sizeof(DevGate)));
+        d_->d_gates_cap = c.gates.size();
+    }
+    if (d_->d_outs_cap < c.outputs.size()) {
+        if (d_->d_outs) HIP_CHECK(hipFree(d_->d_outs));
+        HIP_CHECK(hipMalloc(&d_->d_outs, c.outputs.size() * sizeof(OutRef)));
+        d_->d_outs_cap = c.outputs.size();
+    }
+    if (!c.gates.empty())
+        HIP_CHECK(hipMemcpyAsync(d_->d_gates, c.gates.data(), c.gates.size() * sizeof(DevGate), hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_->d_outs, c.outputs.data(), c.outputs.size() * sizeof(OutRef), hipMemcpyHostToDevice, stream_));
+
+    Timer tall(stats != nullptr, stream_), tbr(stats != nullptr, stream_), tks(stats != nullptr, stream_);
+    tall.mark();
+    // inputs -> slots 0..n_inputs-1 of every expression
+    HIP_CHECK(hipMemcpy2DAsync(d_->store, (size_t)c.n_slots * row_bytes, d_in, (size_t)c.n_inputs * row_bytes,
+                               (size_t)c.n_inputs * row_bytes, batch, hipMemcpyDeviceToDevice, stream_));
+    for (int32_t L = 1; L <= c.n_levels(); L++) {
+        WorkDesc W{};
+        W.gates = d_->d_gates;
+        W.g0 = c.level_offset[L - 1];
+        W.ng = c.level_offset[L] - c.level_offset[L - 1];
+        W.store = d_->store;
+        W.n_slots = c.n_slots;
+        W.item0 = 0;
+        run_items(d_, stream_, W, (int64_t)W.ng * (int64_t)batch, tbr, tks, stats);
+        if (stats) stats->levels++;
+    }
+    const int32_t n_out = (int32_t)c.outputs.size();
+    hipLaunchKernelGGL(k_gather_outputs, dim3((unsigned)(batch * n_out)), dim3(128), 0, stream_, d_->d_outs, n_out,
+                       d_->store, c.n_slots, d_out, (int64_t)batch, stride, p_.n);
+    HIP_CHECK(hipGetLastError());
+    tall.mark();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (stats) {
+        stats->total_ms += tall.sum_ms();
+        stats->blind_rotate_ms += tbr.sum_ms();
+        stats->keyswitch_ms += tks.sum_ms();
+    }
+}
+
+void Evaluator::debug_blind_rotate(size_t count, const Torus32* d_x, Torus32* d_acc, int32_t steps) {
+    if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
+    HIP_CHECK(hipSetDevice(device_));
+    WorkDesc W{};
+    W.flat_a = d_x;
+    W.flat_b = nullptr;
+    W.flat_out = nullptr;
+    W.flat_type = -1;
+    hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)count), dim3(kThreads), d_->br_lds, stream_, d_->K, W,
+                       (Torus32*)nullptr, steps, d_acc);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Evaluator::debug_keyswitch(size_t count, const Torus32* d_u, Torus32* d_out) {
+    if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
+    HIP_CHECK(hipSetDevice(device_));
+    // the kernel reads rows of N+4 ints; repack the caller's N+1 rows
+    Torus32* tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, count * (size_t)(p_.N + 4) * 4));
+    HIP_CHECK(hipMemcpy2DAsync(tmp, (size_t)(p_.N + 4) * 4, d_u, (size_t)(p_.N + 1) * 4, (size_t)(p_.N + 1) * 4, count,
+                               hipMemcpyDeviceToDevice, stream_));
+    WorkDesc W{};
+    hipLaunchKernelGGL(k_keyswitch_generic, dim3((unsigned)count), dim3(kThreads), d_->ks_lds, stream_, d_->K, W, tmp,
+                       d_out);
+    hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(stream_);
+    (void)hipFree(tmp);
+    HIP_CHECK(e);
+}
+
+}  // namespace ieache

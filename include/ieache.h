@@ -1,0 +1,184 @@
+/*
+ * ieache.h -- C ABI of the MI355X-native evaluator for the IE-ACHE Cloud path.
+ *
+ * Drop-in boundary for the hot path of kennethsoh/IE-ACHE: the homomorphic ALU
+ * in Cloud/cloud.c and the libtfhe gate bootstrapping beneath it.  Plain C
+ * types only, caller-allocated buffers, no exceptions cross this boundary:
+ * every function returns 0 on success or a negative IEACHE_E* code (the
+ * process-contract function returns the reference's exit codes 0 / 126), and
+ * ieache_last_error() holds the message.  A context is not thread-safe; use one
+ * per process per GPU.
+ *
+ * Sample layout: one LWE sample = int32[n+1] = a[0..n-1], b (Torus32).  Host
+ * buffers are packed rows of n+1; DEVICE buffers are rows of
+ * ieache_lwe_stride() int32 (n+1 rounded up to a multiple of 4).
+ *
+ * Each entry point names the reference interface it replaces.
+ */
+#ifndef IEACHE_H
+#define IEACHE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IEACHE_EINVAL (-22)   /* bad argument / unsupported parameter set */
+#define IEACHE_EIO (-5)       /* file missing, short or malformed */
+#define IEACHE_ENODEV (-19)   /* no usable GPU / HIP failure */
+#define IEACHE_ENOMEM (-12)
+
+/* TFHE parameter set; replaces TFheGateBootstrappingParameterSet as read from
+ * the key header (Cloud/cloud.c:666-669, Keygen/keygen.c:22-23). */
+typedef struct ieache_params {
+    int32_t n, N, k, l, Bgbit, ks_t, ks_basebit;
+    double lwe_alpha_min, lwe_alpha_max, tlwe_alpha_min, tlwe_alpha_max;
+} ieache_params;
+
+/* libtfhe >= 1.1 new_default_gate_bootstrapping_parameters(110) (keygen.c:22-23):
+ * n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2, sigma 2^-15 / 2^-25. */
+void ieache_default_params(ieache_params* out);
+
+typedef struct ieache_stats {
+    double total_ms;          /* GPU timeline of the call (HIP events on the evaluator's stream) */
+    double blind_rotate_ms;   /* sum over blind-rotation launches */
+    double keyswitch_ms;      /* sum over key-switch launches */
+    int64_t blind_rotate_launches;
+    int64_t keyswitch_launches;
+    int64_t bootstraps;       /* bootsAND/bootsXOR-equivalent gate instances evaluated */
+    int64_t levels;
+} ieache_stats;
+
+/* circuit kinds = the branches of main() in Cloud/cloud.c */
+#define IEACHE_CIRC_ADD 1     /* A+B                cloud.c:870-1190  */
+#define IEACHE_CIRC_SUB 2     /* A+(~B+1)           cloud.c:1196-1807 */
+#define IEACHE_CIRC_RSUB 3    /* B+(~A+1)           cloud.c:1809-2365 */
+#define IEACHE_CIRC_MUL 4     /* A*B, double width  cloud.c:2366-2718 */
+#define IEACHE_CIRC_MULADD 5  /* (A*B)+C, the compute_final() chaining of
+                                 Cloud/dragonfly_cipher_cloud.py:1300-1327 fused (64-bit A,B) */
+
+/* gate types = libtfhe boot-gates.cpp entry points used by cloud.c:30-43,159 */
+#define IEACHE_GATE_AND 0
+#define IEACHE_GATE_XOR 1
+#define IEACHE_GATE_OR 2
+#define IEACHE_GATE_NAND 3
+
+typedef struct ieache_circuit_info {
+    int32_t n_inputs;    /* samples per expression: A bits, B bits, 32-sample carry word [, C bits] */
+    int32_t n_outputs;   /* samples per expression, LSB first */
+    int32_t n_slots;     /* wire-store rows per expression on the device */
+    int32_t depth;       /* ASAP levels */
+    int32_t max_width;
+    int64_t bootstraps, n_and, n_xor;
+} ieache_circuit_info;
+
+const char* ieache_version(void);
+const char* ieache_last_error(void);
+int ieache_device_count(void);
+
+/* ------------------------------------------------------------------ *
+ * 1. Process contract.  Replaces subprocess.call("./cloud")           *
+ *    (Cloud/dragonfly_cipher_cloud.py:1233,1248,1263,1278) = main()   *
+ *    of Cloud/cloud.c:650-2720.  Reads cloud.key, nbit.key,           *
+ *    cloud.data, operator.txt in `workdir`; writes answer.data        *
+ *    (352 samples, or exactly 64 = failure marker checked at          *
+ *    dragonfly_cipher_cloud.py:1295); appends averagestandard.txt on  *
+ *    MUL.  Returns 0 or 126 like the reference, or IEACHE_E*.         *
+ * ------------------------------------------------------------------ */
+int ieache_cloud_run(const char* workdir);
+
+/* ------------------------------------------------------------------ *
+ * 2. Context: cloud key resident on one GPU.  Replaces                *
+ *    new_tfheGateBootstrappingCloudKeySet_fromFile (cloud.c:656-658), *
+ *    without the per-call reload.                                     *
+ * ------------------------------------------------------------------ */
+typedef struct ieache_ctx ieache_ctx;
+
+/* from a cloud.key file */
+ieache_ctx* ieache_ctx_create(const char* cloud_key_path, int device);
+/* from raw arrays on the host: bk [n][(k+1)l][k+1][N], ksk [kN][t][base][n+1] */
+ieache_ctx* ieache_ctx_create_raw(const ieache_params* p, const int32_t* bk, const int32_t* ksk, int device);
+/* from raw arrays already in this GPU's memory (e.g. an RCCL broadcast buffer) */
+ieache_ctx* ieache_ctx_create_device(const ieache_params* p, const int32_t* d_bk, const int32_t* d_ksk, int device);
+void ieache_ctx_destroy(ieache_ctx* ctx);
+int ieache_ctx_params(const ieache_ctx* ctx, ieache_params* out);
+int ieache_lwe_stride(const ieache_ctx* ctx);
+/* the HIP stream the evaluator launches on (hipStream_t as void*) */
+void* ieache_ctx_stream(const ieache_ctx* ctx);
+/* same contract as ieache_cloud_run but with this context's resident key */
+int ieache_ctx_cloud_run(ieache_ctx* ctx, const char* workdir);
+/* tuning / test knobs */
+int ieache_ctx_set_chunk(ieache_ctx* ctx, int64_t gate_instances_per_launch);
+int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
+const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx);
+
+/* ------------------------------------------------------------------ *
+ * 3. Batch evaluation: `batch` independent expressions through one    *
+ *    circuit, level by level.  Replaces the add()/mul32()/mul64()/    *
+ *    mul128()/split() call trees of cloud.c:18-647 and their use in   *
+ *    main().  bits: 16 (generalised add(...,16,...)), 32, 64, 128,    *
+ *    256 for ADD/SUB/RSUB; 32/64/128 for MUL; 64 for MULADD.          *
+ * ------------------------------------------------------------------ */
+int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out);
+/* host buffers: in [batch][n_inputs][n+1], out [batch][n_outputs][n+1] */
+int ieache_eval_batch(ieache_ctx* ctx, int kind, int bits, size_t batch, const int32_t* in_lwe, int32_t* out_lwe,
+                      ieache_stats* stats);
+/* device buffers: rows of ieache_lwe_stride() int32 */
+int ieache_eval_batch_device(ieache_ctx* ctx, int kind, int bits, size_t batch, const int32_t* d_in, int32_t* d_out,
+                             ieache_stats* stats);
+/* `count` independent gates: out[i] = gate(a[i], b[i]); replaces bootsAND /
+ * bootsXOR / bootsOR / bootsNAND (cloud.c:30-43,159).  Device rows. */
+int ieache_gates_device(ieache_ctx* ctx, int gate_type, size_t count, const int32_t* d_a, const int32_t* d_b,
+                        int32_t* d_out, ieache_stats* stats);
+/* host rows of n+1 */
+int ieache_gates(ieache_ctx* ctx, int gate_type, size_t count, const int32_t* a, const int32_t* b, int32_t* out,
+                 ieache_stats* stats);
+/* plaintext simulation of the levelised circuit (host only, no GPU): bits in/out 0/1 */
+int ieache_circuit_simulate(int kind, int bits, const uint8_t* in_bits, uint8_t* out_bits);
+
+/* stage hooks for parity tests (host rows): blind rotation from the
+ * test-vector after `steps` CMux steps (<0: all n) -> acc [count][2][N];
+ * key switch u [count][N+1] -> out [count][n+1] */
+int ieache_debug_blind_rotate(ieache_ctx* ctx, size_t count, const int32_t* x, int32_t* acc, int32_t steps);
+int ieache_debug_keyswitch(ieache_ctx* ctx, size_t count, const int32_t* u, int32_t* out);
+
+/* ------------------------------------------------------------------ *
+ * 4. CPU tools around the path (no GPU): what Keygen/keygen.c:22-51,  *
+ *    Client1/alice.c:116-191 and Output/verif.c:41-76 get from        *
+ *    libtfhe.  Needed to produce and check ciphertexts without it.    *
+ * ------------------------------------------------------------------ */
+/* raw key material; any output pointer may be NULL to skip it */
+int ieache_keygen_raw(const ieache_params* p, const uint32_t* seed_words, int n_seed_words, int32_t* lwe_key /*[n]*/,
+                      int32_t* tlwe_key /*[kN]*/, int32_t* bk, int32_t* ksk);
+/* keygen.c equivalent: writes secret.key, cloud.key, nbit.key into `dir`
+ * (seeds {314,1592,657} / {314,1592,888} as keygen.c:30,34 when seeds are NULL) */
+int ieache_keygen_files(const char* dir, const ieache_params* p, const uint32_t* seed, int n_seed,
+                        const uint32_t* nbit_seed, int n_nbit_seed);
+/* bootsSymEncrypt / bootsSymDecrypt over arrays of bits; rows of n+1 */
+int ieache_encrypt_bits(const ieache_params* p, const int32_t* lwe_key, const uint8_t* bits, size_t count,
+                        uint64_t seed, int32_t* out);
+int ieache_decrypt_bits(const ieache_params* p, const int32_t* lwe_key, const int32_t* samples, size_t count,
+                        uint8_t* bits);
+/* key files -> raw arrays (sizes from ieache_params; pass NULL to query params only) */
+int ieache_read_secret_key(const char* path, ieache_params* p, int32_t* lwe_key, int32_t* tlwe_key);
+int ieache_read_cloud_key(const char* path, ieache_params* p, int32_t* bk, int32_t* ksk);
+int ieache_write_cloud_key(const char* path, const ieache_params* p, const int32_t* bk, const int32_t* ksk);
+int ieache_write_secret_key(const char* path, const ieache_params* p, const int32_t* lwe_key, const int32_t* tlwe_key,
+                            const int32_t* bk, const int32_t* ksk);
+/* LweSample streams (cloud.data / answer.data): rows of n+1 */
+int ieache_read_samples(const char* path, int32_t n, size_t first, size_t count, int32_t* out);
+int ieache_write_samples(const char* path, int32_t n, size_t count, const int32_t* rows, int append);
+/* alice.c equivalent: one operand -> 352 samples appended to `cloud_data_path`:
+ * sign code + bit size under the nbit key, 8 value words + zero carry word
+ * under the secret key (alice.c:116-191).  words: 8 x uint32, LSW first. */
+int ieache_alice(const char* secret_key_path, const char* nbit_key_path, const char* cloud_data_path, int append,
+                 uint32_t sign_code, uint32_t bit_size, const uint32_t* words, uint64_t seed);
+/* verif.c decrypt step: answer.data -> sign code, bit size, 8 value words + carry word */
+int ieache_verif(const char* secret_key_path, const char* nbit_key_path, const char* answer_data_path,
+                 uint32_t* sign_code, uint32_t* bit_size, uint32_t* words9);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,632 @@
+/*
+ * oracle/tfhe_oracle.c -- CPU restatement of libtfhe gate bootstrapping as
+ * used by /root/reference/Cloud/cloud.c (call sites cloud.c:21-48,56,62,159).
+ *
+ * TEST INFRASTRUCTURE ONLY (see tfhe_oracle.h).  "parity unpinned" at
+ * ciphertext level: libtfhe itself (github.com/tfhe/tfhe master, un-pinned,
+ * README.md:36-48) is not in /root/reference; every function below follows
+ * the upstream file named in its comment as restated in SURVEY.md App. A.
+ *
+ * Plain C11, no dependencies.  gcc -O2 -fPIC -shared.
+ */
+#define _GNU_SOURCE
+#include "tfhe_oracle.h"
+#include <math.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* Goldilocks field p = 2^64 - 2^32 + 1, used for an EXACT negacyclic  */
+/* product: every true coefficient is bounded by                       */
+/* (k+1)*l*N*(Bg/2)*2^31 < 2^51 << p/2, so no wrap occurs.             */
+/* ------------------------------------------------------------------ */
+#define GL_P 0xFFFFFFFF00000001ULL
+#define GL_EPS 0xFFFFFFFFULL /* 2^64 mod p */
+
+static inline uint64_t gl_add(uint64_t a, uint64_t b)
+{
+    uint64_t r = a + b;
+    if (r < a) r += GL_EPS; /* wrapped past 2^64 */
+    if (r >= GL_P) r -= GL_P;
+    return r;
+}
+static inline uint64_t gl_sub(uint64_t a, uint64_t b)
+{
+    uint64_t r = a - b;
+    if (a < b) r -= GL_EPS; /* borrowed 2^64 */
+    return r;
+}
+static inline uint64_t gl_mul(uint64_t a, uint64_t b)
+{
+    unsigned __int128 x = (unsigned __int128)a * b;
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t hh = hi >> 32, hl = hi & 0xFFFFFFFFULL;
+    uint64_t t0 = lo - hh; /* 2^96 = -1 */
+    if (lo < hh) t0 -= GL_EPS;
+    uint64_t t1 = hl * GL_EPS; /* 2^64 = 2^32-1 */
+    uint64_t r = t0 + t1;
+    if (r < t1) r += GL_EPS;
+    if (r >= GL_P) r -= GL_P;
+    return r;
+}
+static uint64_t gl_pow(uint64_t b, uint64_t e)
+{
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = gl_mul(r, b);
+        b = gl_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+static inline uint64_t gl_from_i64(int64_t v) { return v >= 0 ? (uint64_t)v : GL_P - (uint64_t)(-v); }
+static inline int64_t gl_center(uint64_t v) { return v > GL_P / 2 ? -(int64_t)(GL_P - v) : (int64_t)v; }
+
+typedef struct {
+    int32_t N, logN;
+    uint64_t *psi_rev;     /* psi^{bitrev(i)} */
+    uint64_t *psi_inv_rev; /* psi^{-bitrev(i)} */
+    uint64_t n_inv;
+} gl_plan;
+
+static uint32_t bitrev(uint32_t x, int bits)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+static void gl_plan_init(gl_plan *pl, int32_t N)
+{
+    pl->N = N;
+    pl->logN = 0;
+    while ((1 << pl->logN) < N) pl->logN++;
+    pl->psi_rev = (uint64_t *)malloc(sizeof(uint64_t) * N);
+    pl->psi_inv_rev = (uint64_t *)malloc(sizeof(uint64_t) * N);
+    /* 7 generates the multiplicative group of the Goldilocks field */
+    uint64_t psi = gl_pow(7, (GL_P - 1) / (2 * (uint64_t)N));
+    uint64_t psi_inv = gl_pow(psi, GL_P - 2);
+    uint64_t a = 1, b = 1;
+    for (int32_t i = 0; i < N; i++) {
+        uint32_t r = bitrev((uint32_t)i, pl->logN);
+        pl->psi_rev[r] = a;
+        pl->psi_inv_rev[r] = b;
+        a = gl_mul(a, psi);
+        b = gl_mul(b, psi_inv);
+    }
+    pl->n_inv = gl_pow((uint64_t)N, GL_P - 2);
+}
+static void gl_plan_free(gl_plan *pl)
+{
+    free(pl->psi_rev);
+    free(pl->psi_inv_rev);
+}
+/* negacyclic forward transform, natural order in, bit-reversed out */
+static void gl_ntt(const gl_plan *pl, uint64_t *a)
+{
+    int32_t N = pl->N, t = N;
+    for (int32_t m = 1; m < N; m <<= 1) {
+        t >>= 1;
+        for (int32_t i = 0; i < m; i++) {
+            int32_t j1 = 2 * i * t;
+            uint64_t S = pl->psi_rev[m + i];
+            for (int32_t j = j1; j < j1 + t; j++) {
+                uint64_t U = a[j], V = gl_mul(a[j + t], S);
+                a[j] = gl_add(U, V);
+                a[j + t] = gl_sub(U, V);
+            }
+        }
+    }
+}
+/* inverse: bit-reversed in, natural out, scaled by 1/N */
+static void gl_intt(const gl_plan *pl, uint64_t *a)
+{
+    int32_t N = pl->N, t = 1;
+    for (int32_t m = N; m > 1; m >>= 1) {
+        int32_t h = m >> 1, j1 = 0;
+        for (int32_t i = 0; i < h; i++) {
+            uint64_t S = pl->psi_inv_rev[h + i];
+            for (int32_t j = j1; j < j1 + t; j++) {
+                uint64_t U = a[j], V = a[j + t];
+                a[j] = gl_add(U, V);
+                a[j + t] = gl_mul(gl_sub(U, V), S);
+            }
+            j1 += 2 * t;
+        }
+        t <<= 1;
+    }
+    for (int32_t j = 0; j < N; j++) a[j] = gl_mul(a[j], pl->n_inv);
+}
+
+/* ------------------------------------------------------------------ */
+/* Approximate FP64 FFT back-end (what libtfhe's                        */
+/* tGswFFTExternMulToTLwe does: N/2-point complex transform of the      */
+/* folded, twisted polynomial).  Not exact; never a parity target.      */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int32_t N, M, logM;     /* M = N/2 complex points */
+    double *tw_re, *tw_im;  /* twist: exp(i*pi*j/N), j<M */
+    double *w_re, *w_im;    /* exp(-2*pi*i*j/M), j<M/2 */
+} fft_plan;
+
+static void fft_plan_init(fft_plan *pl, int32_t N)
+{
+    pl->N = N;
+    pl->M = N / 2;
+    pl->logM = 0;
+    while ((1 << pl->logM) < pl->M) pl->logM++;
+    pl->tw_re = (double *)malloc(sizeof(double) * pl->M);
+    pl->tw_im = (double *)malloc(sizeof(double) * pl->M);
+    pl->w_re = (double *)malloc(sizeof(double) * (pl->M / 2 + 1));
+    pl->w_im = (double *)malloc(sizeof(double) * (pl->M / 2 + 1));
+    for (int32_t j = 0; j < pl->M; j++) {
+        pl->tw_re[j] = cos(M_PI * j / N);
+        pl->tw_im[j] = sin(M_PI * j / N);
+    }
+    for (int32_t j = 0; j < pl->M / 2; j++) {
+        pl->w_re[j] = cos(-2.0 * M_PI * j / pl->M);
+        pl->w_im[j] = sin(-2.0 * M_PI * j / pl->M);
+    }
+}
+static void fft_plan_free(fft_plan *pl)
+{
+    free(pl->tw_re);
+    free(pl->tw_im);
+    free(pl->w_re);
+    free(pl->w_im);
+}
+/* forward DIF: natural in, bit-reversed out (no permutation pass) */
+static void fft_fwd(const fft_plan *pl, double *re, double *im)
+{
+    int32_t M = pl->M;
+    for (int32_t half = M / 2, stride = 1; half >= 1; half >>= 1, stride <<= 1) {
+        for (int32_t base = 0; base < M; base += 2 * half) {
+            for (int32_t j = 0; j < half; j++) {
+                int32_t a = base + j, b = a + half;
+                double wr = pl->w_re[j * stride], wi = pl->w_im[j * stride];
+                double ur = re[a], ui = im[a], vr = re[b], vi = im[b];
+                re[a] = ur + vr;
+                im[a] = ui + vi;
+                double dr = ur - vr, di = ui - vi;
+                re[b] = dr * wr - di * wi;
+                im[b] = dr * wi + di * wr;
+            }
+        }
+    }
+}
+/* inverse DIT: bit-reversed in, natural out, unscaled */
+static void fft_inv(const fft_plan *pl, double *re, double *im)
+{
+    int32_t M = pl->M;
+    for (int32_t half = 1, stride = M / 2; half < M; half <<= 1, stride >>= 1) {
+        for (int32_t base = 0; base < M; base += 2 * half) {
+            for (int32_t j = 0; j < half; j++) {
+                int32_t a = base + j, b = a + half;
+                double wr = pl->w_re[j * stride], wi = -pl->w_im[j * stride];
+                double vr = re[b] * wr - im[b] * wi, vi = re[b] * wi + im[b] * wr;
+                double ur = re[a], ui = im[a];
+                re[a] = ur + vr;
+                im[a] = ui + vi;
+                re[b] = ur - vr;
+                im[b] = ui - vi;
+            }
+        }
+    }
+}
+/* int poly (N) -> folded/twisted spectrum (M complex) */
+static void fft_from_int(const fft_plan *pl, const int32_t *p, double *re, double *im)
+{
+    int32_t M = pl->M;
+    for (int32_t j = 0; j < M; j++) {
+        double x = (double)p[j], y = (double)p[j + M];
+        re[j] = x * pl->tw_re[j] - y * pl->tw_im[j];
+        im[j] = x * pl->tw_im[j] + y * pl->tw_re[j];
+    }
+    fft_fwd(pl, re, im);
+}
+/* spectrum -> Torus32 poly (rounded, wrapped to 32 bits) */
+static void fft_to_torus(const fft_plan *pl, double *re, double *im, int32_t *out)
+{
+    int32_t M = pl->M;
+    fft_inv(pl, re, im);
+    double s = 1.0 / M;
+    for (int32_t j = 0; j < M; j++) {
+        double x = (re[j] * pl->tw_re[j] + im[j] * pl->tw_im[j]) * s;
+        double y = (im[j] * pl->tw_re[j] - re[j] * pl->tw_im[j]) * s;
+        out[j] = (int32_t)(uint32_t)(uint64_t)(int64_t)llrint(x);
+        out[j + M] = (int32_t)(uint32_t)(uint64_t)(int64_t)llrint(y);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+struct orc_cloudkey {
+    orc_params p;
+    int32_t *bk;      /* [n][(k+1)l][k+1][N] */
+    int32_t *ksk;     /* [kN][t][base][n+1] */
+    int mode;
+    gl_plan ntt;
+    uint64_t *bk_ntt; /* same shape as bk */
+    int have_fft;
+    fft_plan fft;
+    double *bk_fft;   /* [n][(k+1)l][k+1][2][M] */
+    uint64_t nboot;
+};
+
+static size_t bk_count(const orc_params *p)
+{
+    return (size_t)p->n * (p->k + 1) * p->l * (p->k + 1) * p->N;
+}
+static size_t ksk_count(const orc_params *p)
+{
+    return (size_t)p->k * p->N * p->ks_t * ((size_t)1 << p->ks_basebit) * (p->n + 1);
+}
+
+orc_cloudkey *orc_cloudkey_new(const orc_params *p, const int32_t *bk, const int32_t *ksk)
+{
+    if (p->k != 1 || (p->N & (p->N - 1)) || p->N < 4) return NULL;
+    orc_cloudkey *ck = (orc_cloudkey *)calloc(1, sizeof(*ck));
+    ck->p = *p;
+    size_t nb = bk_count(p), nk = ksk_count(p);
+    ck->bk = (int32_t *)malloc(nb * sizeof(int32_t));
+    ck->ksk = (int32_t *)malloc(nk * sizeof(int32_t));
+    memcpy(ck->bk, bk, nb * sizeof(int32_t));
+    memcpy(ck->ksk, ksk, nk * sizeof(int32_t));
+    gl_plan_init(&ck->ntt, p->N);
+    ck->bk_ntt = (uint64_t *)malloc(nb * sizeof(uint64_t));
+    for (size_t poly = 0; poly < nb / p->N; poly++) {
+        uint64_t *d = ck->bk_ntt + poly * p->N;
+        const int32_t *s = ck->bk + poly * p->N;
+        for (int32_t j = 0; j < p->N; j++) d[j] = gl_from_i64(s[j]);
+        gl_ntt(&ck->ntt, d);
+    }
+    ck->mode = ORC_POLYMUL_NTT;
+    return ck;
+}
+void orc_cloudkey_free(orc_cloudkey *ck)
+{
+    if (!ck) return;
+    free(ck->bk);
+    free(ck->ksk);
+    free(ck->bk_ntt);
+    gl_plan_free(&ck->ntt);
+    if (ck->have_fft) {
+        fft_plan_free(&ck->fft);
+        free(ck->bk_fft);
+    }
+    free(ck);
+}
+void orc_cloudkey_set_polymul(orc_cloudkey *ck, int mode)
+{
+    ck->mode = mode;
+    if (mode == ORC_POLYMUL_FFT && !ck->have_fft) {
+        const orc_params *p = &ck->p;
+        fft_plan_init(&ck->fft, p->N);
+        size_t npoly = bk_count(p) / p->N;
+        ck->bk_fft = (double *)malloc(npoly * p->N * sizeof(double));
+        for (size_t poly = 0; poly < npoly; poly++)
+            fft_from_int(&ck->fft, ck->bk + poly * p->N, ck->bk_fft + poly * p->N,
+                         ck->bk_fft + poly * p->N + p->N / 2);
+        ck->have_fft = 1;
+    }
+}
+const orc_params *orc_cloudkey_params(const orc_cloudkey *ck) { return &ck->p; }
+uint64_t orc_cloudkey_bootstrap_count(const orc_cloudkey *ck) { return ck->nboot; }
+
+/* ---- libtfhe numeric-functions.cpp ---- */
+int32_t orc_modswitch_to_torus32(int32_t mu, int32_t Msize)
+{
+    uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+    uint64_t phase64 = (uint64_t)(int64_t)mu * interv;
+    return (int32_t)(phase64 >> 32);
+}
+int32_t orc_modswitch_from_torus32(int32_t phase, int32_t Msize)
+{
+    uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+    uint64_t half = interv / 2;
+    uint64_t phase64 = ((uint64_t)(uint32_t)phase << 32) + half; /* wraps at 2^64 */
+    return (int32_t)(phase64 / interv);
+}
+
+/* ---- libtfhe polynomials_arithmetic: torusPolynomialMulByXai ---- */
+static void poly_mul_by_xai(int32_t N, int32_t *out, int32_t a, const int32_t *in)
+{
+    if (a < N) {
+        for (int32_t i = 0; i < a; i++) out[i] = (int32_t)(0u - (uint32_t)in[i - a + N]);
+        for (int32_t i = a; i < N; i++) out[i] = in[i - a];
+    } else {
+        int32_t aa = a - N;
+        for (int32_t i = 0; i < aa; i++) out[i] = in[i - aa + N];
+        for (int32_t i = aa; i < N; i++) out[i] = (int32_t)(0u - (uint32_t)in[i - aa]);
+    }
+}
+/* torusPolynomialMulByXaiMinusOne */
+static void poly_mul_by_xai_minus_one(int32_t N, int32_t *out, int32_t a, const int32_t *in)
+{
+    if (a < N) {
+        for (int32_t i = 0; i < a; i++)
+            out[i] = (int32_t)(0u - (uint32_t)in[i - a + N] - (uint32_t)in[i]);
+        for (int32_t i = a; i < N; i++) out[i] = (int32_t)((uint32_t)in[i - a] - (uint32_t)in[i]);
+    } else {
+        int32_t aa = a - N;
+        for (int32_t i = 0; i < aa; i++)
+            out[i] = (int32_t)((uint32_t)in[i - aa + N] - (uint32_t)in[i]);
+        for (int32_t i = aa; i < N; i++)
+            out[i] = (int32_t)(0u - (uint32_t)in[i - aa] - (uint32_t)in[i]);
+    }
+}
+
+/* exact schoolbook negacyclic product with int32 wraparound */
+static void negacyclic_schoolbook_acc(int32_t N, uint32_t *acc, const int32_t *small,
+                                      const int32_t *big)
+{
+    for (int32_t i = 0; i < N; i++) {
+        uint32_t s = (uint32_t)small[i];
+        if (!s) continue;
+        for (int32_t j = 0; j < N - i; j++) acc[i + j] += s * (uint32_t)big[j];
+        for (int32_t j = N - i; j < N; j++) acc[i + j - N] -= s * (uint32_t)big[j];
+    }
+}
+
+void orc_negacyclic_mul(int mode, int32_t N, int32_t *out, const int32_t *small, const int32_t *big)
+{
+    if (mode == ORC_POLYMUL_SCHOOLBOOK) {
+        uint32_t *acc = (uint32_t *)calloc(N, sizeof(uint32_t));
+        negacyclic_schoolbook_acc(N, acc, small, big);
+        for (int32_t j = 0; j < N; j++) out[j] = (int32_t)acc[j];
+        free(acc);
+    } else if (mode == ORC_POLYMUL_NTT) {
+        gl_plan pl;
+        gl_plan_init(&pl, N);
+        uint64_t *a = (uint64_t *)malloc(sizeof(uint64_t) * N), *b = (uint64_t *)malloc(sizeof(uint64_t) * N);
+        for (int32_t j = 0; j < N; j++) {
+            a[j] = gl_from_i64(small[j]);
+            b[j] = gl_from_i64(big[j]);
+        }
+        gl_ntt(&pl, a);
+        gl_ntt(&pl, b);
+        for (int32_t j = 0; j < N; j++) a[j] = gl_mul(a[j], b[j]);
+        gl_intt(&pl, a);
+        for (int32_t j = 0; j < N; j++) out[j] = (int32_t)(uint32_t)(uint64_t)gl_center(a[j]);
+        free(a);
+        free(b);
+        gl_plan_free(&pl);
+    } else {
+        fft_plan pl;
+        fft_plan_init(&pl, N);
+        int32_t M = N / 2;
+        double *a = (double *)malloc(sizeof(double) * N), *b = (double *)malloc(sizeof(double) * N);
+        double *c = (double *)malloc(sizeof(double) * N);
+        fft_from_int(&pl, small, a, a + M);
+        fft_from_int(&pl, big, b, b + M);
+        for (int32_t j = 0; j < M; j++) {
+            c[j] = a[j] * b[j] - a[j + M] * b[j + M];
+            c[j + M] = a[j] * b[j + M] + a[j + M] * b[j];
+        }
+        fft_to_torus(&pl, c, c + M, out);
+        free(a);
+        free(b);
+        free(c);
+        fft_plan_free(&pl);
+    }
+}
+
+/* ---- lwe-bootstrapping-functions-fft.cpp: tfhe_bootstrap_woKS_FFT steps ---- */
+int32_t orc_modswitch_sample(const orc_cloudkey *ck, const int32_t *x, int32_t *bara)
+{
+    const int32_t n = ck->p.n, Nx2 = 2 * ck->p.N;
+    for (int32_t i = 0; i < n; i++) bara[i] = orc_modswitch_from_torus32(x[i], Nx2);
+    return orc_modswitch_from_torus32(x[n], Nx2);
+}
+
+void orc_blind_rotate_init(const orc_cloudkey *ck, int32_t *acc, int32_t barb, int32_t mu)
+{
+    const int32_t N = ck->p.N, k = ck->p.k;
+    int32_t *testvect = (int32_t *)malloc(sizeof(int32_t) * N);
+    for (int32_t i = 0; i < N; i++) testvect[i] = mu;
+    memset(acc, 0, sizeof(int32_t) * (size_t)k * N);
+    if (barb != 0)
+        poly_mul_by_xai(N, acc + (size_t)k * N, 2 * N - barb, testvect);
+    else
+        memcpy(acc + (size_t)k * N, testvect, sizeof(int32_t) * N);
+    free(testvect);
+}
+
+/* tgsw-functions.cpp: tGswTorus32PolynomialDecompH */
+static void decomp_h(const orc_params *p, int32_t *dec /*[l][N]*/, const int32_t *poly)
+{
+    const int32_t N = p->N, l = p->l, Bgbit = p->Bgbit;
+    const uint32_t halfBg = 1u << (Bgbit - 1), mask = (1u << Bgbit) - 1;
+    uint32_t offset = 0;
+    for (int32_t i = 1; i <= l; i++) offset += halfBg << (32 - i * Bgbit);
+    for (int32_t j = 0; j < N; j++) {
+        uint32_t v = (uint32_t)poly[j] + offset;
+        for (int32_t q = 0; q < l; q++) {
+            int32_t decal = 32 - (q + 1) * Bgbit;
+            dec[(size_t)q * N + j] = (int32_t)((v >> decal) & mask) - (int32_t)halfBg;
+        }
+    }
+}
+
+/* tfhe_MuxRotate_FFT: acc += BK_i (x) ((X^barai - 1) acc)
+ * (tLweMulByXaiMinusOne, tGswFFTExternMulToTLwe, tLweAddTo) */
+void orc_blind_rotate_step(const orc_cloudkey *ck, int32_t *acc, int32_t i, int32_t barai)
+{
+    const orc_params *p = &ck->p;
+    const int32_t N = p->N, k = p->k, l = p->l, kpl = (k + 1) * l;
+    if (barai == 0) return; /* libtfhe skips; exact arithmetic makes it a no-op anyway */
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(k + 1) * N);
+    int32_t *dec = (int32_t *)malloc(sizeof(int32_t) * (size_t)kpl * N);
+    for (int32_t c = 0; c <= k; c++)
+        poly_mul_by_xai_minus_one(N, tmp + (size_t)c * N, barai, acc + (size_t)c * N);
+    for (int32_t c = 0; c <= k; c++) decomp_h(p, dec + (size_t)c * l * N, tmp + (size_t)c * N);
+    const size_t bk_i = (size_t)i * kpl * (k + 1) * N;
+    if (ck->mode == ORC_POLYMUL_SCHOOLBOOK) {
+        for (int32_t c = 0; c <= k; c++) {
+            uint32_t *out = (uint32_t *)(acc + (size_t)c * N);
+            for (int32_t row = 0; row < kpl; row++)
+                negacyclic_schoolbook_acc(N, out, dec + (size_t)row * N,
+                                          ck->bk + bk_i + ((size_t)row * (k + 1) + c) * N);
+        }
+    } else if (ck->mode == ORC_POLYMUL_NTT) {
+        uint64_t *dn = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)kpl * N);
+        uint64_t *s = (uint64_t *)malloc(sizeof(uint64_t) * N);
+        for (int32_t row = 0; row < kpl; row++) {
+            uint64_t *d = dn + (size_t)row * N;
+            for (int32_t j = 0; j < N; j++) d[j] = gl_from_i64(dec[(size_t)row * N + j]);
+            gl_ntt(&ck->ntt, d);
+        }
+        for (int32_t c = 0; c <= k; c++) {
+            memset(s, 0, sizeof(uint64_t) * N);
+            for (int32_t row = 0; row < kpl; row++) {
+                const uint64_t *b = ck->bk_ntt + bk_i + ((size_t)row * (k + 1) + c) * N;
+                const uint64_t *d = dn + (size_t)row * N;
+                for (int32_t j = 0; j < N; j++) s[j] = gl_add(s[j], gl_mul(d[j], b[j]));
+            }
+            gl_intt(&ck->ntt, s);
+            uint32_t *out = (uint32_t *)(acc + (size_t)c * N);
+            for (int32_t j = 0; j < N; j++) out[j] += (uint32_t)(uint64_t)gl_center(s[j]);
+        }
+        free(dn);
+        free(s);
+    } else {
+        const int32_t M = N / 2;
+        double *df = (double *)malloc(sizeof(double) * (size_t)kpl * N);
+        double *s = (double *)malloc(sizeof(double) * N);
+        int32_t *r = (int32_t *)malloc(sizeof(int32_t) * N);
+        for (int32_t row = 0; row < kpl; row++)
+            fft_from_int(&ck->fft, dec + (size_t)row * N, df + (size_t)row * N,
+                         df + (size_t)row * N + M);
+        for (int32_t c = 0; c <= k; c++) {
+            memset(s, 0, sizeof(double) * N);
+            for (int32_t row = 0; row < kpl; row++) {
+                const double *b = ck->bk_fft + bk_i + ((size_t)row * (k + 1) + c) * N;
+                const double *d = df + (size_t)row * N;
+                for (int32_t j = 0; j < M; j++) {
+                    s[j] += d[j] * b[j] - d[j + M] * b[j + M];
+                    s[j + M] += d[j] * b[j + M] + d[j + M] * b[j];
+                }
+            }
+            fft_to_torus(&ck->fft, s, s + M, r);
+            uint32_t *out = (uint32_t *)(acc + (size_t)c * N);
+            for (int32_t j = 0; j < N; j++) out[j] += (uint32_t)r[j];
+        }
+        free(df);
+        free(s);
+        free(r);
+    }
+    free(tmp);
+    free(dec);
+}
+
+void orc_blind_rotate(const orc_cloudkey *ck, int32_t *acc, const int32_t *bara)
+{
+    for (int32_t i = 0; i < ck->p.n; i++) orc_blind_rotate_step(ck, acc, i, bara[i]);
+}
+
+/* tlwe-functions.cpp: tLweExtractLweSampleIndex(index=0) */
+void orc_sample_extract(const orc_cloudkey *ck, int32_t *u, const int32_t *acc)
+{
+    const int32_t N = ck->p.N, k = ck->p.k;
+    for (int32_t c = 0; c < k; c++) {
+        const int32_t *a = acc + (size_t)c * N;
+        u[(size_t)c * N] = a[0];
+        for (int32_t j = 1; j < N; j++) u[(size_t)c * N + j] = (int32_t)(0u - (uint32_t)a[N - j]);
+    }
+    u[(size_t)k * N] = acc[(size_t)k * N];
+}
+
+/* lwe-keyswitch-functions.cpp: lweKeySwitch / lweKeySwitchTranslate_fromArray */
+void orc_keyswitch(const orc_cloudkey *ck, int32_t *out, const int32_t *u)
+{
+    const orc_params *p = &ck->p;
+    const int32_t n = p->n, Nin = p->k * p->N, t = p->ks_t, basebit = p->ks_basebit;
+    const int32_t base = 1 << basebit, mask = base - 1;
+    const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+    uint32_t *r = (uint32_t *)out;
+    int32_t b_in = u[Nin];
+    for (int32_t j = 0; j < n; j++) r[j] = 0;
+    r[n] = (uint32_t)b_in;
+    for (int32_t i = 0; i < Nin; i++) {
+        uint32_t aibar = (uint32_t)u[i] + prec_offset;
+        for (int32_t j = 0; j < t; j++) {
+            uint32_t aij = (aibar >> (32 - (j + 1) * basebit)) & (uint32_t)mask;
+            if (aij != 0) {
+                const int32_t *row = ck->ksk + (((size_t)i * t + j) * base + aij) * (n + 1);
+                for (int32_t q = 0; q <= n; q++) r[q] -= (uint32_t)row[q];
+            }
+        }
+    }
+}
+
+/* lwe-bootstrapping-functions-fft.cpp: tfhe_bootstrap_FFT with mu = 1/8 */
+void orc_bootstrap(const orc_cloudkey *ck, int32_t *out, const int32_t *x)
+{
+    const orc_params *p = &ck->p;
+    int32_t *bara = (int32_t *)malloc(sizeof(int32_t) * p->n);
+    int32_t *acc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->k + 1) * p->N);
+    int32_t *u = (int32_t *)malloc(sizeof(int32_t) * ((size_t)p->k * p->N + 1));
+    const int32_t mu = orc_modswitch_to_torus32(1, 8);
+    int32_t barb = orc_modswitch_sample(ck, x, bara);
+    orc_blind_rotate_init(ck, acc, barb, mu);
+    orc_blind_rotate(ck, acc, bara);
+    orc_sample_extract(ck, u, acc);
+    orc_keyswitch(ck, out, u);
+    ((orc_cloudkey *)ck)->nboot++;
+    free(bara);
+    free(acc);
+    free(u);
+}
+
+/* ---- boot-gates.cpp ---- */
+void orc_gate_constant(const orc_cloudkey *ck, int32_t *out, int32_t value)
+{
+    const int32_t n = ck->p.n, MU = orc_modswitch_to_torus32(1, 8);
+    memset(out, 0, sizeof(int32_t) * n);
+    out[n] = value ? MU : (int32_t)(0u - (uint32_t)MU);
+}
+void orc_gate_not(const orc_cloudkey *ck, int32_t *out, const int32_t *ca)
+{
+    for (int32_t j = 0; j <= ck->p.n; j++) out[j] = (int32_t)(0u - (uint32_t)ca[j]);
+}
+void orc_gate_copy(const orc_cloudkey *ck, int32_t *out, const int32_t *ca)
+{
+    if (out != ca) memmove(out, ca, sizeof(int32_t) * (ck->p.n + 1));
+}
+/* t = (0, cst) + sa*ca + sb*cb, then bootstrap */
+static void gate2(const orc_cloudkey *ck, int32_t *out, int32_t cst, int32_t sa, const int32_t *ca,
+                  int32_t sb, const int32_t *cb)
+{
+    const int32_t n = ck->p.n;
+    int32_t *t = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
+    for (int32_t j = 0; j <= n; j++)
+        t[j] = (int32_t)((uint32_t)sa * (uint32_t)ca[j] + (uint32_t)sb * (uint32_t)cb[j]);
+    t[n] = (int32_t)((uint32_t)t[n] + (uint32_t)cst);
+    orc_bootstrap(ck, out, t);
+    free(t);
+}
+void orc_gate_and(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb)
+{
+    gate2(ck, out, orc_modswitch_to_torus32(-1, 8), 1, ca, 1, cb);
+}
+void orc_gate_xor(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb)
+{
+    gate2(ck, out, orc_modswitch_to_torus32(1, 4), 2, ca, 2, cb);
+}
+void orc_gate_or(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb)
+{
+    gate2(ck, out, orc_modswitch_to_torus32(1, 8), 1, ca, 1, cb);
+}
+void orc_gate_nand(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb)
+{
+    gate2(ck, out, orc_modswitch_to_torus32(1, 8), -1, ca, -1, cb);
+}
+
+int32_t orc_lwe_phase(const int32_t *sample, const int32_t *key, int32_t n)
+{
+    uint32_t acc = (uint32_t)sample[n];
+    for (int32_t i = 0; i < n; i++) acc -= (uint32_t)sample[i] * (uint32_t)key[i];
+    return (int32_t)acc;
+}
