@@ -1,0 +1,69 @@
+"""Multi-GPU plumbing for the evaluator: one process per GPU, expressions
+sharded across ranks, keys broadcast once.
+
+The path has NO data-path collective: batch elements are independent
+expressions and the cloud key is read-only, so after the one-time broadcast of
+BK/KSK (RCCL over xGMI with backend "nccl"; "gloo" in the CPU tests) ranks never
+talk again until results are gathered on the host side.
+"""
+import os
+
+import numpy as np
+
+
+def init_distributed(backend=None):
+    """-> (rank, world, local_rank, dist-or-None) from the torchrun environment."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return rank, world, local_rank, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        kw["device_id"] = torch.device("cuda", local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank, dist
+
+
+def shard_slice(total, rank, world):
+    """Contiguous total/world slice of the expression batch owned by `rank`
+    (the first total % world ranks take one extra)."""
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return slice(start, start + base + (1 if rank < extra else 0))
+
+
+def broadcast_cloud_key(params, keys, device, dist, src=0):
+    """One-time replication of the raw cloud key (+ the LWE secret key used to
+    make synthetic inputs in benchmarks) from rank `src`.
+
+    keys: dict(bk, ksk, lwe_key) of numpy int32 on `src`, None elsewhere.
+    Returns torch int32 tensors (bk, ksk, lwe_key) on `device`."""
+    import torch
+    rank = dist.get_rank() if dist is not None else 0
+    if rank == src:
+        out = [torch.from_numpy(np.ascontiguousarray(keys[k]).reshape(-1)).to(device) for k in ("bk", "ksk", "lwe_key")]
+    else:
+        out = [torch.empty(c, dtype=torch.int32, device=device) for c in (params.bk_count, params.ksk_count, params.n)]
+    if dist is not None:
+        for t in out:
+            dist.broadcast(t, src)
+    return out
+
+
+def gather_to_rank0(dist, local):
+    """Host-side gather of per-rank result arrays (numpy, concatenated along axis 0) on rank 0."""
+    if dist is None:
+        return local
+    objs = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(local, objs, dst=0)
+    if dist.get_rank() != 0:
+        return None
+    return np.concatenate(objs, axis=0)

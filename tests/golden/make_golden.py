@@ -1,0 +1,104 @@
+"""Regenerates the committed golden vectors under tests/golden/.
+
+The reference holds no ciphertext-level vectors (no tests directory, libtfhe
+not vendored), so these are produced HERE by the exact-integer CPU oracle
+(oracle/) on keys from the product's keygen tool; they pin both the oracle and
+the HIP path against regressions.  Plaintext-level vectors come from the
+reference's own canned operands (Client1/process.c:94-99,122-129,152-163,
+185-204: value = 2^(bits-2), sign code 0 or 2).
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import ieache_amd as ia  # noqa: E402
+from ieache_amd import tools  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def toy_vectors():
+    p = ia.default_params().copy(n=6, N=64)
+    seed = (2024, 10, 3)
+    k = tools.keygen_raw(p, seed)
+    ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, k["bk"], k["ksk"])
+    a_bits = np.array([0, 0, 1, 1], dtype=np.uint8)
+    b_bits = np.array([0, 1, 0, 1], dtype=np.uint8)
+    ca = tools.encrypt_bits(p, k["lwe_key"], a_bits, 1001)
+    cb = tools.encrypt_bits(p, k["lwe_key"], b_bits, 1002)
+    out = {"params": np.array([p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit], dtype=np.int32),
+           "seed": np.array(seed, dtype=np.uint32), "lwe_key": k["lwe_key"], "bk": k["bk"], "ksk": k["ksk"],
+           "ca": ca, "cb": cb, "a_bits": a_bits, "b_bits": b_bits}
+    for g in ("and", "xor", "or", "nand"):
+        out["gate_" + g] = np.stack([ck.gate(g, ca[i], cb[i]) for i in range(4)])
+    # stages of one bootstrap
+    bara, barb = ck.modswitch(ca[3])
+    acc0 = ck.blind_rotate_init(barb)
+    acc1 = ck.blind_rotate_step(acc0, 0, bara[0])
+    accn = ck.blind_rotate(acc0, bara)
+    u = ck.sample_extract(accn)
+    out.update(bara=bara, barb=np.int32(barb), acc0=acc0, acc1=acc1, accn=accn, extracted=u,
+               keyswitched=ck.keyswitch(u))
+    # add(nb_bits=4): x=0b1011, y=0b0110, carry-in 1
+    x = tools.encrypt_bits(p, k["lwe_key"], tools.int_to_bits(0b1011, 4), 1003)
+    y = tools.encrypt_bits(p, k["lwe_key"], tools.int_to_bits(0b0110, 4), 1004)
+    c = tools.encrypt_bits(p, k["lwe_key"], np.array([1], dtype=np.uint8), 1005)
+    s, co = ck.add(x, y, c, 4)
+    out.update(add_x=x, add_y=y, add_c=c, add_sum=s, add_carry=co)
+    np.savez_compressed(os.path.join(HERE, "toy_vectors.npz"), **out)
+    print("toy_vectors.npz written")
+
+
+def full_size_kat():
+    p = ia.default_params()
+    seed = (314, 1592, 657)  # Keygen/keygen.c:30
+    k = tools.keygen_raw(p, seed)
+    ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, k["bk"], k["ksk"])
+    ca = tools.encrypt_bits(p, k["lwe_key"], np.array([1, 0], dtype=np.uint8), 2001)
+    cb = tools.encrypt_bits(p, k["lwe_key"], np.array([1, 1], dtype=np.uint8), 2002)
+    np.savez_compressed(os.path.join(HERE, "full_gate_kat.npz"),
+                        seed=np.array(seed, dtype=np.uint32), key_sha256=np.array(digest(k["lwe_key"], k["bk"], k["ksk"])),
+                        lwe_key=k["lwe_key"], ca=ca, cb=cb,
+                        gate_and=np.stack([ck.gate("and", ca[i], cb[i]) for i in range(2)]),
+                        gate_xor=np.stack([ck.gate("xor", ca[i], cb[i]) for i in range(2)]))
+    print("full_gate_kat.npz written")
+
+
+def plaintext_kats():
+    kats = []
+    for bits in (32, 64, 128, 256):
+        v = 1 << (bits - 2)  # process.c
+        for op, name in ((1, "+"), (2, "-"), (4, "*")):
+            if op == 4 and bits == 256:
+                kats.append({"op": op, "bits": bits, "a": str(v), "sa": 0, "b": str(v), "sb": 0, "exit": 126})
+                continue
+            for sa in (0, 2):       # process.c:80,86 sign codes: 0 positive, 2 negative
+                for sb in (0, 2):
+                    A, B = (-v if sa else v), (-v if sb else v)
+                    r = A + B if op == 1 else (A - B if op == 2 else A * B)
+                    kats.append({"op": op, "bits": bits, "a": str(v), "sa": sa, "b": str(v), "sb": sb,
+                                 "exit": 0, "expect": str(r)})
+    with open(os.path.join(HERE, "plaintext_kats.json"), "w") as f:
+        json.dump(kats, f, indent=0)
+    print("plaintext_kats.json written,", len(kats), "cases")
+
+
+if __name__ == "__main__":
+    toy_vectors()
+    full_size_kat()
+    plaintext_kats()

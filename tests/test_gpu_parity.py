@@ -1,0 +1,289 @@
+"""-m gpu: the HIP path through the C ABI against the CPU oracle.
+
+P2 (bit-exact): every LWE coefficient the GPU produces equals the exact-integer
+oracle's.  P1: outputs decrypt to integer arithmetic.  """
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_extension_loaded_and_device_present(ia):
+    assert os.path.exists(ia.library_path())
+    assert ia.device_count() >= 1
+
+
+@pytest.mark.parametrize("n,N", [(5, 64), (8, 256), (16, 1024)])
+def test_blind_rotate_stage_bit_exact(gpu_ctx, n, N):
+    kb, ctx = gpu_ctx(n, N)
+    x = kb.enc(np.random.default_rng(n).integers(0, 2, size=6), 7)
+    x[5] = 0  # all bara_i = 0: every CMux step is skipped
+    for steps in (0, 1, 3, -1):
+        acc = ctx.debug_blind_rotate(x, steps)
+        for i in range(x.shape[0]):
+            bara, barb = kb.ck.modswitch(x[i])
+            ref = kb.ck.blind_rotate_init(barb)
+            for s in range(kb.p.n if steps < 0 else steps):
+                ref = kb.ck.blind_rotate_step(ref, s, bara[s])
+            assert np.array_equal(ref, acc[i]), (steps, i)
+
+
+@pytest.mark.parametrize("n,N", [(5, 64), (16, 1024), (630, 1024)])
+def test_keyswitch_stage_bit_exact(gpu_ctx, n, N):
+    kb, ctx = gpu_ctx(n, N)
+    rng = np.random.default_rng(0)
+    u = rng.integers(-2 ** 31, 2 ** 31, size=(5, N + 1), dtype=np.int64).astype(np.int32)
+    u[3] = 0                # every digit zero except the rounding offset's
+    u[4, :N] = -(1 << 15)   # a_i + 2^15 wraps to 0: no row subtracted at all
+    out = ctx.debug_keyswitch(u)
+    for i in range(u.shape[0]):
+        assert np.array_equal(kb.ck.keyswitch(u[i]), out[i]), i
+    assert not out[4, :n].any() and out[4, n] == u[4, N]
+
+
+@pytest.mark.parametrize("n,N", [(5, 64), (16, 1024)])
+def test_gates_bit_exact_and_truth_tables(ia, gpu_ctx, n, N):
+    kb, ctx = gpu_ctx(n, N)
+    a_bits = np.array([0, 0, 1, 1] * 3, dtype=np.uint8)
+    b_bits = np.array([0, 1, 0, 1] * 3, dtype=np.uint8)
+    a, b = kb.enc(a_bits, 11), kb.enc(b_bits, 12)
+    for name, gt, f in (("and", ia.GATE_AND, a_bits & b_bits), ("xor", ia.GATE_XOR, a_bits ^ b_bits),
+                        ("or", ia.GATE_OR, a_bits | b_bits), ("nand", ia.GATE_NAND, 1 - (a_bits & b_bits))):
+        st = ia.Stats()
+        out = ctx.gates(gt, a, b, st)
+        assert st.bootstraps == 12
+        assert np.array_equal(kb.dec(out), f), name
+        for i in range(12):
+            assert np.array_equal(kb.ck.gate(name, a[i], b[i]), out[i]), (name, i)
+
+
+def test_full_size_gates_match_golden_and_oracle(ia, O, gpu_ctx):
+    """n=630, N=1024: committed KAT + a batch that must decrypt correctly."""
+    z = np.load(os.path.join(G, "full_gate_kat.npz"))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(int(v) for v in z["seed"]))
+    assert np.array_equal(ctx.gates(ia.GATE_AND, z["ca"], z["cb"]), z["gate_and"])
+    assert np.array_equal(ctx.gates(ia.GATE_XOR, z["ca"], z["cb"]), z["gate_xor"])
+    rng = np.random.default_rng(1)
+    bits = rng.integers(0, 2, size=(2, 300)).astype(np.uint8)
+    a, b = kb.enc(bits[0], 21), kb.enc(bits[1], 22)
+    out = ctx.gates(ia.GATE_XOR, a, b)
+    assert np.array_equal(kb.dec(out), bits[0] ^ bits[1])
+    for i in (0, 299):
+        assert np.array_equal(kb.ck.gate("xor", a[i], b[i]), out[i])
+    # chunked launches give the same bits
+    ctx.set_chunk(64)
+    assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), out)
+    ctx.set_chunk(16384)
+
+
+def test_toy_golden_vectors(ia):
+    z = np.load(os.path.join(G, "toy_vectors.npz"))
+    n, N, k, l, Bgbit, t, bb = (int(v) for v in z["params"])
+    p = ia.default_params().copy(n=n, N=N, k=k, l=l, Bgbit=Bgbit, ks_t=t, ks_basebit=bb)
+    with ia.Context.from_arrays(p, z["bk"], z["ksk"]) as ctx:
+        for g, gt in (("and", ia.GATE_AND), ("xor", ia.GATE_XOR), ("or", ia.GATE_OR), ("nand", ia.GATE_NAND)):
+            assert np.array_equal(ctx.gates(gt, z["ca"], z["cb"]), z["gate_" + g]), g
+        assert np.array_equal(ctx.debug_blind_rotate(z["ca"][3:4], 0)[0], z["acc0"])
+        assert np.array_equal(ctx.debug_blind_rotate(z["ca"][3:4], 1)[0], z["acc1"])
+        assert np.array_equal(ctx.debug_blind_rotate(z["ca"][3:4], -1)[0], z["accn"])
+        assert np.array_equal(ctx.debug_keyswitch(z["extracted"])[0], z["keyswitched"])
+        # add(nb_bits=4) through the generalised ADD circuit: inputs x, y, carry word
+        inp = np.concatenate([z["add_x"], z["add_y"], np.repeat(z["add_c"], 32, axis=0)])[None]
+        out = ctx.eval_batch(ia.CIRC_ADD, 4, inp)
+        assert np.array_equal(out[0], z["add_sum"])
+
+
+def _inputs(kb, kind, bits, values, seed):
+    """values: list of (a, b[, c]) -> encrypted circuit inputs [batch][n_inputs][n+1]."""
+    import ieache_amd as ia
+    from ieache_amd.tools import int_to_bits
+    info = ia.circuit_info(kind, bits)
+    inb = np.zeros((len(values), info.n_inputs), dtype=np.uint8)
+    for e, v in enumerate(values):
+        inb[e, :bits] = int_to_bits(v[0], bits)
+        inb[e, bits:2 * bits] = int_to_bits(v[1], bits)
+        if kind == 5:
+            inb[e, 2 * bits + 32:] = int_to_bits(v[2], 2 * bits)
+    return kb.enc(inb, seed)
+
+
+def _oracle_values(kb, op, neg, bits, inp):
+    """Run the oracle's sequential cloud.c restatement on one expression's inputs."""
+    S = kb.p.n + 1
+    W = bits // 32
+    o1 = np.zeros((8, 32, S), np.int32)
+    o2 = np.zeros((8, 32, S), np.int32)
+    o1[:W] = inp[:bits].reshape(W, 32, S)
+    o2[:W] = inp[bits:2 * bits].reshape(W, 32, S)
+    rc, out = kb.ck.cloud_values(op, neg, bits, o1, o2, inp[2 * bits:2 * bits + 32])
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("kind,op,neg,bits", [(1, 1, 0, 32), (1, 1, 0, 64), (2, 2, 0, 32), (2, 2, 0, 128), (3, 1, 1, 64),
+                                              (1, 1, 0, 256), (2, 1, 2, 256)])
+def test_add_sub_circuits_bit_exact(ia, gpu_ctx, kind, op, neg, bits):
+    kb, ctx = gpu_ctx(4, 1024)
+    from ieache_amd.tools import bits_to_int
+    rng = np.random.default_rng(bits + kind)
+    m = 1 << bits
+    vals = [(int.from_bytes(rng.bytes(bits // 8), "little"), int.from_bytes(rng.bytes(bits // 8), "little")) for _ in range(3)]
+    vals += [(m - 1, 1), (1 << (bits - 2), 1 << (bits - 2))]  # carry through every bit; process.c operands
+    inp = _inputs(kb, kind, bits, vals, 5)
+    st = ia.Stats()
+    out = ctx.eval_batch(kind, bits, inp, st)
+    info = ia.circuit_info(kind, bits)
+    assert st.bootstraps == info.bootstraps * len(vals) and st.levels == info.depth
+    dec = kb.dec(out)
+    for e, (a, b) in enumerate(vals):
+        exp = {1: a + b, 2: a - b, 3: b - a}[kind] % m
+        assert bits_to_int(dec[e]) == exp
+    ref = _oracle_values(kb, op, neg, bits, inp[0])
+    assert np.array_equal(ref[:bits // 32].reshape(bits, -1), out[0])
+
+
+def test_add16_generalisation_bit_exact(ia, gpu_ctx):
+    """BASELINE.json configs[1]: add(..., nb_bits=16, ...) (cloud.c:18)."""
+    kb, ctx = gpu_ctx(4, 1024)
+    from ieache_amd.tools import bits_to_int
+    vals = [(0xFFFF, 1), (0x1234, 0xEDCB), (0, 0), (40000, 30000)]
+    inp = _inputs(kb, 1, 16, vals, 6)
+    out = ctx.eval_batch(1, 16, inp)
+    dec = kb.dec(out)
+    for e, (a, b) in enumerate(vals):
+        assert bits_to_int(dec[e]) == (a + b) & 0xFFFF
+        s, _ = kb.ck.add(inp[e, :16], inp[e, 16:32], inp[e, 32:33], 16)
+        assert np.array_equal(s, out[e])
+
+
+def test_mul32_bit_exact(ia, gpu_ctx):
+    kb, ctx = gpu_ctx(4, 1024)
+    from ieache_amd.tools import bits_to_int
+    vals = [(0xFFFFFFFF, 0xFFFFFFFF), (1 << 30, 1 << 30), (0xDEADBEEF, 0x12345678)]
+    inp = _inputs(kb, 4, 32, vals, 8)
+    st = ia.Stats()
+    out = ctx.eval_batch(4, 32, inp, st)
+    assert st.bootstraps == 11264 * 3 and st.levels == 255
+    dec = kb.dec(out)
+    for e, (a, b) in enumerate(vals):
+        assert bits_to_int(dec[e]) == a * b
+    ref = _oracle_values(kb, 4, 0, 32, inp[2])
+    assert np.array_equal(ref[:2].reshape(64, -1), out[2])
+
+
+def test_mul64_and_muladd_small_ring(ia, gpu_ctx):
+    """64-bit MUL (2x mul64 + split) and the fused a*b+c, on a small ring so the oracle is quick."""
+    kb, ctx = gpu_ctx(4, 64)
+    from ieache_amd.tools import bits_to_int
+    a, b, c = 0xFEDCBA9876543210, 0x0F1E2D3C4B5A6978, (1 << 127) | 0x1234567890ABCDEF
+    inp = _inputs(kb, 4, 64, [(a, b), (1 << 62, 1 << 62)], 9)
+    out = ctx.eval_batch(4, 64, inp)
+    dec = kb.dec(out)
+    assert bits_to_int(dec[0]) == a * b and bits_to_int(dec[1]) == 1 << 124
+    ref = _oracle_values(kb, 4, 0, 64, inp[0])
+    assert np.array_equal(ref[:4].reshape(128, -1), out[0])
+    inp = _inputs(kb, 5, 64, [(a, b, c)], 10)
+    out = ctx.eval_batch(5, 64, inp)
+    assert bits_to_int(kb.dec(out)[0]) == (a * b + c) % (1 << 128)
+    # oracle: stage 1 MUL64, stage 2 ADD at 128 bits with the answer as operand 1
+    S = kb.p.n + 1
+    st1 = _oracle_values(kb, 4, 0, 64, inp[0])
+    o2 = np.zeros((8, 32, S), np.int32)
+    o2[:4] = inp[0, 160:].reshape(4, 32, S)
+    rc, st2 = kb.ck.cloud_values(1, 0, 128, st1[:8], o2, inp[0, 128:160])
+    assert rc == 0 and np.array_equal(st2[:4].reshape(128, -1), out[0])
+
+
+def test_mul128_decrypts(ia, gpu_ctx):
+    kb, ctx = gpu_ctx(4, 64)
+    from ieache_amd.tools import bits_to_int
+    a = (1 << 126) | 0xFFFFFFFFFFFFFFFFFFFFFFFF
+    b = (1 << 127) | 0x123456789ABCDEF0FEDCBA9
+    inp = _inputs(kb, 4, 128, [(a, b), (1 << 126, 1 << 126)], 12)
+    st = ia.Stats()
+    out = ctx.eval_batch(4, 128, inp, st)
+    assert st.levels == 1601 and st.bootstraps == 2 * 121184
+    dec = kb.dec(out)
+    assert bits_to_int(dec[0]) == a * b and bits_to_int(dec[1]) == 1 << 252  # process.c:152-163
+    ref = _oracle_values(kb, 4, 0, 128, inp[1])
+    assert np.array_equal(ref[:8].reshape(256, -1), out[1])
+
+
+def test_device_buffer_api_matches_host_api(ia, gpu_ctx):
+    import torch
+    kb, ctx = gpu_ctx(4, 1024)
+    inp = _inputs(kb, 1, 32, [(123456789, 987654321), (7, 9)], 13)
+    host = ctx.eval_batch(1, 32, inp)
+    stride = ctx.lwe_stride
+    d_in = torch.zeros((2, 96, stride), dtype=torch.int32, device="cuda")
+    d_in[:, :, :kb.p.n + 1] = torch.from_numpy(inp).cuda()
+    d_out = torch.zeros((2, 32, stride), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.eval_batch_device(1, 32, 2, d_in.data_ptr(), d_out.data_ptr())
+    assert np.array_equal(d_out.cpu().numpy()[:, :, :kb.p.n + 1], host)
+    # keys handed over as device pointers (the RCCL-broadcast path)
+    bk = torch.from_numpy(np.ascontiguousarray(kb.bk)).cuda()
+    ksk = torch.from_numpy(np.ascontiguousarray(kb.ksk)).cuda()
+    torch.cuda.synchronize()
+    with ia.Context.from_device_pointers(kb.p, bk.data_ptr(), ksk.data_ptr()) as ctx2:
+        assert np.array_equal(ctx2.eval_batch(1, 32, inp), host)
+
+
+def _run_file_contract(ia, tmp_path, op_code, operator, bits, a, sa, b, sb, use_subprocess=False, ctx=None):
+    from ieache_amd import tools
+    tools.alice(tmp_path, sa, bits, a, seed=31)
+    tools.alice(tmp_path, sb, bits, b, seed=32, append=True)
+    rc, size, ok = ia.compute(operator, tmp_path, ctx=ctx, use_subprocess=use_subprocess)
+    return rc, size, ok
+
+
+def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
+    """keygen -> alice x2 -> compute() -> verif, on the reference's canned operands
+    (tests/golden/plaintext_kats.json from Client1/process.c), every sign case."""
+    from ieache_amd import tools
+    p = ia.default_params().copy(n=6, N=64)
+    tools.keygen_files(tmp_path, p)
+    S = 4 * p.n + 16
+    kats = json.load(open(os.path.join(G, "plaintext_kats.json")))
+    _, bk, ksk = tools.read_cloud_key(tmp_path / "cloud.key")
+    ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, bk, ksk)
+    with ia.Context.from_file(tmp_path / "cloud.key") as ctx:
+        for kat in kats:
+            if kat["bits"] == 128 and kat["op"] == 4 and (kat["sa"], kat["sb"]) != (0, 0):
+                continue  # one sign case of the deepest circuit is enough
+            operator = {1: 1, 2: 2, 4: 3}[kat["op"]]
+            rc, size, ok = _run_file_contract(ia, tmp_path, kat["op"], operator, kat["bits"], int(kat["a"]), kat["sa"],
+                                              int(kat["b"]), kat["sb"], ctx=ctx)
+            assert rc == kat["exit"]
+            if rc == 126:  # Cannot multiply 256 bit number (cloud.c:860-864): 64 samples only
+                assert size == 64 * S and not ok
+                continue
+            assert size == 352 * S and ok
+            code, bit_size, words = tools.verif(tmp_path)
+            assert bit_size == (2 * kat["bits"] if kat["op"] == 4 else kat["bits"])
+            assert tools.verif_interpret(kat["op"], code, bit_size, words) == int(kat["expect"]), kat
+            # P2 through the file boundary: value samples equal the oracle's on the same cloud.data
+            data = tools.read_samples(tmp_path / "cloud.data", p.n).reshape(22, 32, p.n + 1)
+            neg = {0: 0, 2: 1}[kat["sa"]] + kat["sb"]
+            rc2, ref = ck.cloud_values(kat["op"], neg, kat["bits"], data[2:10], data[13:21], data[10])
+            ans = tools.read_samples(tmp_path / "answer.data", p.n).reshape(11, 32, p.n + 1)
+            assert rc2 == 0 and np.array_equal(ans[2:], ref), kat
+    # the `cloud` executable shim honours the same contract (exit code, files in cwd)
+    rc, size, ok = _run_file_contract(ia, tmp_path, 1, 1, 32, 1 << 30, 0, 1 << 30, 0, use_subprocess=True)
+    assert (rc, ok) == (0, True)
+    assert tools.verif_interpret(1, *tools.verif(tmp_path)) == 1 << 31
+    assert (tmp_path / "timings.txt").exists()
+    rc, size, ok = _run_file_contract(ia, tmp_path, 4, 3, 256, 5, 0, 5, 0, use_subprocess=True)
+    assert rc == 126 and size == 64 * S
+    # chaining (compute_final): (a*b) then + c through answer.data -> cloud.data
+    _run_file_contract(ia, tmp_path, 4, 3, 32, 1000, 0, 2000, 0)
+    tools.alice(tmp_path, 0, 32, 77, seed=33)  # third operand alone in cloud.data
+    rc, size, ok = ia.compute_final(1, tmp_path, flip=True)
+    assert rc == 0 and ok
+    code, bit_size, words = tools.verif(tmp_path)
+    assert bit_size == 64 and tools.verif_interpret(1, code, bit_size, words) == 1000 * 2000 + 77
+    assert (tmp_path / "averagestandard.txt").exists()  # MUL timing log (cloud.c:2467-2471)

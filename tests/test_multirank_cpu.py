@@ -1,0 +1,82 @@
+"""The N>1 path on CPU: two gloo ranks broadcast the cloud key, shard a batch of
+expressions with no data-path collective, and gather on the host.  (On the GPU
+box the same functions run over RCCL; there is nothing else between ranks.)"""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import hashlib, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch
+    import ieache_amd as ia
+    from ieache_amd import parallel, tools
+    rank, world, local_rank, dist = parallel.init_distributed("gloo")
+    assert world == 2 and dist is not None
+    p = ia.default_params().copy(n=7, N=32)
+    keys = tools.keygen_raw(p, (9, 9, 9)) if rank == 0 else None
+    bk, ksk, lwe = parallel.broadcast_cloud_key(p, keys, torch.device("cpu"), dist)
+    ref = tools.keygen_raw(p, (9, 9, 9))   # every rank can recompute what rank 0 sent
+    assert np.array_equal(bk.numpy(), ref["bk"].ravel()) and np.array_equal(ksk.numpy(), ref["ksk"].ravel())
+    assert np.array_equal(lwe.numpy(), ref["lwe_key"])
+    # shard 13 expressions of a 16-bit ADD; each rank evaluates only its own slice
+    total, bits = 13, 16
+    rng = np.random.default_rng(0)   # same operands on both ranks
+    a = rng.integers(0, 1 << bits, size=total); b = rng.integers(0, 1 << bits, size=total)
+    sl = parallel.shard_slice(total, rank, world)
+    info = ia.circuit_info(ia.CIRC_ADD, bits)
+    local = []
+    for e in range(sl.start, sl.stop):
+        x = np.zeros(info.n_inputs, dtype=np.uint8)
+        x[:bits] = tools.int_to_bits(int(a[e]), bits); x[bits:2 * bits] = tools.int_to_bits(int(b[e]), bits)
+        local.append(tools.bits_to_int(ia.circuit_simulate(ia.CIRC_ADD, bits, x)))
+    got = parallel.gather_to_rank0(dist, np.array(local, dtype=np.int64))
+    if rank == 0:
+        assert got.tolist() == [int((a[e] + b[e]) %% (1 << bits)) for e in range(total)]
+        print("MULTIRANK_OK", sl, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+def test_shard_slices_cover_batch_exactly():
+    sys.path.insert(0, ROOT)
+    from ieache_amd.parallel import shard_slice
+    for total in (0, 1, 7, 8, 1024, 1025, 8192):
+        for world in (1, 2, 3, 8):
+            sl = [shard_slice(total, r, world) for r in range(world)]
+            assert sl[0].start == 0 and sl[-1].stop == total
+            assert all(sl[i].stop == sl[i + 1].start for i in range(world - 1))
+            sizes = [s.stop - s.start for s in sl]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_slice(1024, 3, 8) == slice(384, 512)  # BASELINE config 4: 128 expressions per GPU
+
+
+def test_two_rank_gloo_broadcast_and_shard(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, _ = pr.communicate()
+        outs.append(out)
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
+    assert "MULTIRANK_OK" in outs[0]
