@@ -20,11 +20,13 @@ FAILURE_SIZE = 162304
 _PKG = os.path.dirname(os.path.abspath(__file__))
 
 
-def compute(operator, workdir=".", ctx=None, use_subprocess=False):
+def compute(operator, workdir=".", ctx=None, use_subprocess=False, failure_size=FAILURE_SIZE):
     """operator: 1 add, 2 subtract, 3 or 4 multiply (both write "4", :1256-1274).
 
     Returns (exit_code, answer_size, ok).  ok is False when answer.data holds
-    64 samples or fewer (the reference then ships the short file and exits)."""
+    64 samples or fewer (the reference then ships the short file and exits).
+    failure_size is the reference's hard-coded 64 x 2536 (n=630); tests on other
+    parameter sets pass 64 x (4n+16)."""
     code = {1: "1", 2: "2", 3: "4", 4: "4"}.get(int(operator))
     if code is None:
         return None, None, False  # :1286-1287 "else: None"
@@ -41,10 +43,10 @@ def compute(operator, workdir=".", ctx=None, use_subprocess=False):
         f.write("\nComputation time: ")
         f.write(str(round(time.perf_counter() - t0, 3)))
     ans_size = os.path.getsize(os.path.join(workdir, "answer.data"))
-    return rc, ans_size, ans_size > FAILURE_SIZE
+    return rc, ans_size, ans_size > failure_size
 
 
-def compute_final(operator, workdir=".", flip=True, ctx=None, use_subprocess=False):
+def compute_final(operator, workdir=".", flip=True, ctx=None, use_subprocess=False, failure_size=FAILURE_SIZE):
     """Second stage of a 3-operand expression (:1300-1327): cloud.data holds the
     third operand; combine it with the previous answer.data and run again."""
     cloud = os.path.join(workdir, "cloud.data")
@@ -57,4 +59,4 @@ def compute_final(operator, workdir=".", flip=True, ctx=None, use_subprocess=Fal
         with open(answer, "rb") as a, open(cloud, "ab") as c:
             shutil.copyfileobj(a, c, 8192)
     os.remove(answer)
-    return compute(operator, workdir, ctx=ctx, use_subprocess=use_subprocess)
+    return compute(operator, workdir, ctx=ctx, use_subprocess=use_subprocess, failure_size=failure_size)

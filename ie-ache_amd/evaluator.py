@@ -6,6 +6,7 @@ first use, and every evaluation entry point needs a GPU.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -76,6 +77,16 @@ def lib():
     if not os.path.exists(path):
         raise IeacheError(-19, "HIP extension %s is missing: run __graft_entry__.build() "
                                "(make -C ie-ache_amd/csrc); there is no CPU fallback" % path)
+    # PyTorch bundles its own HIP runtime under the same SONAME (libamdhip64.so.7) as
+    # /opt/rocm's.  Two HIP runtimes in one process cannot both own the GPU, so when
+    # torch is installed let it load first: the dynamic loader then binds libieache.so
+    # to the runtime already in the process.  (The standalone `cloud` executable has
+    # no torch in-process and uses /opt/rocm's.)
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     i32p, u32p, u8p, vp = C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_void_p
     pp, sp = C.POINTER(Params), C.POINTER(Stats)

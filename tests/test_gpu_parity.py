@@ -237,7 +237,7 @@ def _run_file_contract(ia, tmp_path, op_code, operator, bits, a, sa, b, sb, use_
     from ieache_amd import tools
     tools.alice(tmp_path, sa, bits, a, seed=31)
     tools.alice(tmp_path, sb, bits, b, seed=32, append=True)
-    rc, size, ok = ia.compute(operator, tmp_path, ctx=ctx, use_subprocess=use_subprocess)
+    rc, size, ok = ia.compute(operator, tmp_path, ctx=ctx, use_subprocess=use_subprocess, failure_size=64 * (4 * 6 + 16))
     return rc, size, ok
 
 
@@ -265,10 +265,26 @@ def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
             assert size == 352 * S and ok
             code, bit_size, words = tools.verif(tmp_path)
             assert bit_size == (2 * kat["bits"] if kat["op"] == 4 else kat["bits"])
-            assert tools.verif_interpret(kat["op"], code, bit_size, words) == int(kat["expect"]), kat
+            # value words = the magnitude circuit main() dispatches to (SURVEY 8a truth table)
+            a_mag, b_mag, m = int(kat["a"]), int(kat["b"]), 1 << kat["bits"]
+            neg = {0: 0, 2: 1}[kat["sa"]] + kat["sb"]
+            if kat["op"] == 4:
+                mag = a_mag * b_mag
+            elif (kat["op"] == 1 and neg in (0, 3)) or (kat["op"] == 2 and neg in (1, 2)):
+                mag = (a_mag + b_mag) % m
+            elif (kat["op"] == 2 and neg == 0) or (kat["op"] == 1 and neg == 2):
+                mag = (a_mag - b_mag) % m
+            else:
+                mag = (b_mag - a_mag) % m
+            nw = bit_size // 32
+            assert sum(w << (32 * i) for i, w in enumerate(words[:nw])) == mag, kat
+            assert code == {0: 0, 1: 1, 2: 2, 3: 4}[neg] and words[nw:] == [0] * (9 - nw)
+            # verif.c reads mixed-sign sums as two's complement, so it is only right while
+            # |result| < 2^(bits-1); process.c's 2^(bits-2) operands sit exactly on that edge
+            if abs(int(kat["expect"])) < (1 << (bit_size - 1)):
+                assert tools.verif_interpret(kat["op"], code, bit_size, words) == int(kat["expect"]), kat
             # P2 through the file boundary: value samples equal the oracle's on the same cloud.data
             data = tools.read_samples(tmp_path / "cloud.data", p.n).reshape(22, 32, p.n + 1)
-            neg = {0: 0, 2: 1}[kat["sa"]] + kat["sb"]
             rc2, ref = ck.cloud_values(kat["op"], neg, kat["bits"], data[2:10], data[13:21], data[10])
             ans = tools.read_samples(tmp_path / "answer.data", p.n).reshape(11, 32, p.n + 1)
             assert rc2 == 0 and np.array_equal(ans[2:], ref), kat
@@ -282,7 +298,7 @@ def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
     # chaining (compute_final): (a*b) then + c through answer.data -> cloud.data
     _run_file_contract(ia, tmp_path, 4, 3, 32, 1000, 0, 2000, 0)
     tools.alice(tmp_path, 0, 32, 77, seed=33)  # third operand alone in cloud.data
-    rc, size, ok = ia.compute_final(1, tmp_path, flip=True)
+    rc, size, ok = ia.compute_final(1, tmp_path, flip=True, failure_size=64 * S)
     assert rc == 0 and ok
     code, bit_size, words = tools.verif(tmp_path)
     assert bit_size == 64 and tools.verif_interpret(1, code, bit_size, words) == 1000 * 2000 + 77
