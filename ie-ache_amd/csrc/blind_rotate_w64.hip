@@ -1,0 +1,417 @@
+// Blind rotation for the N=1024 ring, two 64-lane wavefronts per gate.
+//
+// Same mathematics as k_blind_rotate_generic (tfhe_blindRotate_FFT of libtfhe,
+// SURVEY.md App. A steps 2-5) with the exact two-limb FP64 negacyclic transform,
+// re-laid out for CDNA4:
+//   * the 512-point complex transform is 8 x 8 x 8: three radix-8 passes done
+//     entirely in registers (8 points per lane), separated by two transposes
+//     through an 8 KiB per-wave LDS tile -- no workgroup barriers, the wave is
+//     its own workgroup;
+//   * the spectrum stays in registers between the forward transform, the
+//     point-wise multiply-accumulate with BK_i and the inverse transform; BK_i
+//     is stored in exactly the (register, lane) order the forward transform
+//     leaves its output in, so every BK load is one coalesced 1 KiB
+//     global_load_dwordx4 per wave;
+//   * the accumulator (2 x 1024 int32) lives in LDS only because the
+//     X^a rotation needs arbitrary shifts; twiddles are rebuilt from three
+//     per-lane roots of unity instead of tables.
+#include "blind_rotate_w64.h"
+
+#include <cstdlib>
+
+namespace ieache {
+namespace w64 {
+
+using namespace dev;
+
+namespace {
+
+constexpr int kN = 1024, kM = 512;
+constexpr double kR = 0.70710678118654752440;  // 1/sqrt(2)
+
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// forward: multiply by -i ; inverse: by +i
+template <bool INV>
+__device__ __forceinline__ double2 rot90(double2 z) {
+    return INV ? make_double2(-z.y, z.x) : make_double2(z.y, -z.x);
+}
+__device__ __forceinline__ double2 csqr(double2 a) { return make_double2(fma(a.x, a.x, -a.y * a.y), (a.x + a.x) * a.y); }
+// a * b  or  a * conj(b)
+template <bool CONJ>
+__device__ __forceinline__ double2 cmulx(double2 a, double2 b) {
+    return CONJ ? make_double2(fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -a.x * b.y))
+                : make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+
+// 8-point DFT in registers, natural order in and out.  52 FP64 operations.
+template <bool INV>
+__device__ __forceinline__ void dft8(double2 (&x)[8]) {
+    const double2 a0 = cadd(x[0], x[4]), a1 = cadd(x[1], x[5]), a2 = cadd(x[2], x[6]), a3 = cadd(x[3], x[7]);
+    const double2 b0 = csub(x[0], x[4]), t1 = csub(x[1], x[5]), t2 = csub(x[2], x[6]), t3 = csub(x[3], x[7]);
+    // even outputs: DFT4(a)
+    const double2 c0 = cadd(a0, a2), c1 = cadd(a1, a3), c2 = csub(a0, a2), c3 = rot90<INV>(csub(a1, a3));
+    x[0] = cadd(c0, c1);
+    x[4] = csub(c0, c1);
+    x[2] = cadd(c2, c3);
+    x[6] = csub(c2, c3);
+    // odd outputs: DFT4(b), b_j = t_j * W8^j with the 1/sqrt2 factors deferred into the last FMAs
+    const double2 b2 = rot90<INV>(t2);
+    // forward: t1*(1-i), t3*(-1-i) ; inverse: t1*(1+i), t3*(-1+i)
+    const double2 b1 = INV ? make_double2(t1.x - t1.y, t1.x + t1.y) : make_double2(t1.x + t1.y, t1.y - t1.x);
+    const double2 b3 = INV ? make_double2(-t3.x - t3.y, t3.x - t3.y) : make_double2(t3.y - t3.x, -t3.x - t3.y);
+    const double2 e0 = cadd(b0, b2), e2 = csub(b0, b2);
+    const double2 s = cadd(b1, b3), d = rot90<INV>(csub(b1, b3));
+    x[1] = make_double2(fma(kR, s.x, e0.x), fma(kR, s.y, e0.y));
+    x[5] = make_double2(fma(-kR, s.x, e0.x), fma(-kR, s.y, e0.y));
+    x[3] = make_double2(fma(kR, d.x, e2.x), fma(kR, d.y, e2.y));
+    x[7] = make_double2(fma(-kR, d.x, e2.x), fma(-kR, d.y, e2.y));
+}
+
+// x[k] *= t[k] for k >= K0 (CONJ: by the conjugates)
+template <bool CONJ, int K0>
+__device__ __forceinline__ void twiddle_tab(double2 (&x)[8], const double2 (&t)[8]) {
+#pragma unroll
+    for (int k = K0; k < 8; k++) x[k] = cmulx<CONJ>(x[k], t[k]);
+}
+
+// Orders this wave's LDS traffic without a workgroup barrier: the DS instructions of
+// one wave execute in issue order, so only the compiler has to be held back.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool WSYNC>
+__device__ __forceinline__ void tile_sync() {
+    if (WSYNC)
+        wave_sync();
+    else
+        __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Per-lane twiddles, built once per kernel and used by every transform in both
+// directions (the inverse multiplies by the conjugates):
+//   t1[k] = exp(i*pi*lane/1024) * exp(-2*pi*i*lane*k/512)   twist (lane part) x first inter-pass twiddle
+//   t2[k] = exp(-2*pi*i*(lane&7)*k/64), k = 1..7            second inter-pass twiddle
+struct LaneRoots {
+    double2 t1[8];
+    double2 t2[8];  // t2[0] unused
+};
+
+__device__ __forceinline__ LaneRoots make_roots(int lane) {
+    LaneRoots r;
+    double s, c;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // lane/1024 - 2*lane*k/512 = lane*(1 - 4k)/1024
+        sincospi((double)(lane * (1 - 4 * k)) / 1024.0, &s, &c);
+        r.t1[k] = make_double2(c, s);
+        sincospi(-(double)((lane & 7) * k) / 32.0, &s, &c);
+        r.t2[k] = make_double2(c, s);
+    }
+    return r;
+}
+
+// Transpose tiles hold element (h, m, l) -- three 3-bit digits -- at h*72 + m*9 + l.
+// The 9/72 padding makes every ds_write_b128 / ds_read_b128 of both transposes
+// bank-conflict free AND lets each access be "per-lane base + immediate offset".
+constexpr int kTile = 8 * 72;  // double2 elements per tile (9216 B)
+
+// Forward 512-point transform of the twisted polynomial.
+//   in : x[r] = y_{64r+lane} * exp(i*pi*r/16)  (the lane part tL of the twist is applied here)
+//   out: x[k2] = X[k0 + 8*k1 + 64*k2] with lane = 8*k0 + k1
+template <bool WSYNC>
+__device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
+    const int hi = lane >> 3, lo = lane & 7;
+    const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
+    const int blk = hi * 72 + lo;  // (h, l) = (lane>>3, lane&7)
+    dft8<false>(x);                          // over r -> k0
+    twiddle_tab<false, 0>(x, R.t1);          // * tL * w512^(lane*k0)
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) sT[own + 72 * k0] = x[k0];   // element (k0, p1, p0), lane = (p1, p0)
+    tile_sync<WSYNC>();
+#pragma unroll
+    for (int p1 = 0; p1 < 8; p1++) x[p1] = sT[blk + 9 * p1];    // lane = (k0, p0)
+    tile_sync<WSYNC>();
+    dft8<false>(x);                          // over p1 -> k1 ; lane = 8*k0 + p0
+    twiddle_tab<false, 1>(x, R.t2);          // * w64^(p0*k1)
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) sT[blk + 9 * k1] = x[k1];    // element (k0, k1, p0), lane = (k0, p0)
+    tile_sync<WSYNC>();
+    {
+        const int rd = hi * 72 + lo * 9;                         // lane = (k0, k1)
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = sT[rd + q];
+    }
+    tile_sync<WSYNC>();
+    dft8<false>(x);                          // over p0 -> k2 ; lane = 8*k0 + k1
+}
+
+// Inverse of fft512_forward (unnormalised: 512 x), also removing the lane part of the twist:
+//   in : spectrum in the layout fft512_forward produces
+//   out: x[r] = y_{64r+lane} * exp(i*pi*r/16)   (caller multiplies by exp(-i*pi*r/16))
+template <bool WSYNC>
+__device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
+    const int hi = lane >> 3, lo = lane & 7;
+    const int own = hi * 9 + lo, blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
+    dft8<true>(x);  // k2 -> p0 ; lane = (k0, k1)
+#pragma unroll
+    for (int q = 0; q < 8; q++) sT[rd + q] = x[q];              // element (k0, k1, p0)
+    tile_sync<WSYNC>();
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = sT[blk + 9 * k];         // lane = (k0, p0)
+    tile_sync<WSYNC>();
+    twiddle_tab<true, 1>(x, R.t2);
+    dft8<true>(x);  // k1 -> p1 ; lane = 8*k0 + p0
+#pragma unroll
+    for (int p1 = 0; p1 < 8; p1++) sT[blk + 9 * p1] = x[p1];    // element (k0, p1, p0)
+    tile_sync<WSYNC>();
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) x[k0] = sT[own + 72 * k0];   // lane = (p1, p0)
+    tile_sync<WSYNC>();
+    twiddle_tab<true, 0>(x, R.t1);  // conj(tL * w1^k0); the 1/512 is folded into untwist_reg()
+    dft8<true>(x);  // k0 -> r
+}
+
+// exp(i*pi*r/16), r = 0..7: the register part of the twist
+__device__ __forceinline__ double2 twist_reg(int r) {
+    constexpr double C[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                             0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                             0.19509032201612826785};
+    constexpr double S[8] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
+                             0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613,
+                             0.98078528040323044913};
+    return make_double2(C[r], S[r]);
+}
+
+// exp(i*pi*r/16) / 512: multiplying by its conjugate removes the register part of the
+// twist and normalises the inverse transform (exact: a power-of-two scale)
+__device__ __forceinline__ double2 untwist_reg(int r) {
+    const double2 t = twist_reg(r);
+    return make_double2(t.x * (1.0 / 512.0), t.y * (1.0 / 512.0));
+}
+
+// ---- key preparation: BK polynomial -> two-limb spectrum in the w64 register/lane order ----
+// bkf layout: [n][2L rows][q = 2*c + limb][k2 = 8][lane = 64]
+__global__ __launch_bounds__(64) void k_bk_to_spectrum_w64(const Torus32* bk_raw, double2* bkf) {
+    __shared__ __align__(16) double2 sT[kTile];
+    const int lane = threadIdx.x;
+    const LaneRoots R = make_roots(lane);
+    const size_t poly = blockIdx.x;  // (i * 2L + row) * 2 + c
+    const Torus32* src = bk_raw + poly * kN;
+    const size_t irow = poly >> 1, c = poly & 1;
+#pragma unroll 1
+    for (int limb = 0; limb < 2; limb++) {
+        double2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int32_t v0 = src[64 * r + lane], v1 = src[64 * r + lane + kM];
+            const int32_t lo0 = (int16_t)(v0 & 0xFFFF), lo1 = (int16_t)(v1 & 0xFFFF);
+            const int32_t e0 = limb ? (int32_t)(((int64_t)v0 - lo0) >> 16) : lo0;
+            const int32_t e1 = limb ? (int32_t)(((int64_t)v1 - lo1) >> 16) : lo1;
+            x[r] = cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+        }
+        fft512_forward<true>(x, sT, lane, R);
+        double2* dst = bkf + ((irow * 4 + c * 2 + limb) * 8) * 64 + lane;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) dst[k2 * 64] = x[k2];
+    }
+}
+
+// ---- K0..K4: one 128-thread workgroup (two waves) per gate instance ----
+// Wave w decomposes accumulator polynomial w (its 3 digit rows -> 3 forward
+// transforms), owns the spectrum-domain sums of OUTPUT polynomial w (both
+// limbs) and inverse-transforms them.  Each forward spectrum is handed to the
+// partner wave through the producing wave's own (then idle) transpose tile.
+// dynamic LDS: sT [2][kTile] double2 | acc [2][1024] int32 | bara [n] u16
+template <int L, int BGBIT, bool PREFETCH, bool WSYNC>
+__global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf, WorkDesc W,
+                                                           Torus32* ext, int32_t steps, Torus32* dbg_acc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* sT_all = reinterpret_cast<double2*>(smem);
+    int32_t* acc = reinterpret_cast<int32_t*>(sT_all + 2 * kTile);
+    uint16_t* bara = reinterpret_cast<uint16_t*>(acc + 2 * kN);
+    __shared__ int32_t s_barb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double2* sT = sT_all + wave * kTile;
+    const double2* sTp = sT_all + (wave ^ 1) * kTile;
+    const int32_t n = K.n;
+    const int64_t item = (int64_t)blockIdx.x;
+    const GateInst g = resolve(W, W.item0 + item, K.stride);
+    const LaneRoots R = make_roots(lane);
+
+    // K0 + K1: gate pre-combination and mod-switch to Z_2N
+    for (int32_t i = tid; i <= n; i += 128) {
+        const int32_t bar = modswitch2N(combined_coef(g, i, n), 11);
+        if (i < n)
+            bara[i] = (uint16_t)bar;
+        else
+            s_barb = bar;
+    }
+    __syncthreads();
+    // K2: acc = (0, X^{2N-barb} * (mu,...,mu))
+    {
+        const int32_t a0 = (2 * kN - s_barb) & (2 * kN - 1);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int32_t j = 128 * r + tid;
+            acc[j] = 0;
+            acc[kN + j] = ((j - a0) & (2 * kN - 1)) < kN ? kMU : -kMU;
+        }
+    }
+    __syncthreads();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1), maskBg = (1u << BGBIT) - 1;
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    const int32_t nsteps = steps < 0 ? n : steps;
+    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: (x + magic) carries round(x) in its low mantissa bits
+    int32_t* accw = acc + wave * kN;  // the polynomial this wave decomposes and updates
+
+#pragma unroll 1
+    for (int32_t i = 0; i < nsteps; i++) {
+        const int32_t a = bara[i];
+        if (a == 0) continue;  // workgroup-uniform; exact arithmetic makes the step a no-op
+        // BK_i rows [2L][4][8][64]; this wave reads outputs o = 2*wave, 2*wave+1 of every row
+        const double2* __restrict__ bki = bkf + (size_t)i * (2 * L * 4 * kM) + (size_t)(2 * wave) * kM + lane;
+        double2 s[2][8];
+#pragma unroll
+        for (int o = 0; o < 2; o++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[o][k] = make_double2(0.0, 0.0);
+        // (X^a - 1) * acc_w at this lane's 16 coefficients, plus the decomposition offset
+        uint32_t v0[8], v1[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int32_t j = 64 * r + lane;
+            v0[r] = (uint32_t)rot_coef(accw, j, a, kN) - (uint32_t)accw[j] + dec_offset;
+            v1[r] = (uint32_t)rot_coef(accw, j + kM, a, kN) - (uint32_t)accw[j + kM] + dec_offset;
+        }
+#pragma unroll 1
+        for (int q = 0; q < L; q++) {
+            const int sh = 32 - (q + 1) * BGBIT;
+            const double2* __restrict__ bown = bki + (size_t)(wave * L + q) * (4 * kM);
+            const double2* __restrict__ bpar = bki + (size_t)((wave ^ 1) * L + q) * (4 * kM);
+            double2 x[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int32_t e0 = (int32_t)((v0[r] >> sh) & maskBg) - (int32_t)halfBg;
+                const int32_t e1 = (int32_t)((v1[r] >> sh) & maskBg) - (int32_t)halfBg;
+                x[r] = cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            }
+            // BK for our own row, first limb: optionally requested before the transform so
+            // that the L2 round trip overlaps ~1500 cycles of butterflies
+            double2 bpre[8];
+            if (PREFETCH) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) bpre[k] = bown[k * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fft512_forward<WSYNC>(x, sT, lane, R);
+            // hand the spectrum to the partner wave through our own (now idle) tile
+#pragma unroll
+            for (int k = 0; k < 8; k++) sT[k * 64 + lane] = x[k];
+            // own row: s[o] += x * B[own row][2*wave + o]
+            if (!PREFETCH) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) bpre[k] = bown[k * 64];
+            }
+            {
+                double2 b[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) b[k] = bown[(8 + k) * 64];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    s[0][k] = make_double2(fma(x[k].x, bpre[k].x, fma(-x[k].y, bpre[k].y, s[0][k].x)),
+                                           fma(x[k].x, bpre[k].y, fma(x[k].y, bpre[k].x, s[0][k].y)));
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    s[1][k] = make_double2(fma(x[k].x, b[k].x, fma(-x[k].y, b[k].y, s[1][k].x)),
+                                           fma(x[k].x, b[k].y, fma(x[k].y, b[k].x, s[1][k].y)));
+            }
+            __syncthreads();
+            // partner's row
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = sTp[k * 64 + lane];
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                double2 b[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) b[k] = bpar[(o * 8 + k) * 64];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    s[o][k] = make_double2(fma(x[k].x, b[k].x, fma(-x[k].y, b[k].y, s[o][k].x)),
+                                           fma(x[k].x, b[k].y, fma(x[k].y, b[k].x, s[o][k].y)));
+            }
+            __syncthreads();  // partner has read our tile before the next transform reuses it
+        }
+        // back to coefficients, round, recombine the two limbs, accumulate into polynomial `wave`
+        uint32_t lo0[8], lo1[8];
+#pragma unroll
+        for (int limb = 0; limb < 2; limb++) {
+            fft512_inverse<WSYNC>(s[limb], sT, lane, R);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const double2 z = cmulx<true>(s[limb][r], untwist_reg(r));
+                const uint32_t i0 = (uint32_t)__double2loint(z.x + kMagic);
+                const uint32_t i1 = (uint32_t)__double2loint(z.y + kMagic);
+                if (limb == 0) {
+                    lo0[r] = i0;
+                    lo1[r] = i1;
+                } else {
+                    const int32_t j = 64 * r + lane;
+                    accw[j] = (int32_t)((uint32_t)accw[j] + lo0[r] + (i0 << 16));
+                    accw[j + kM] = (int32_t)((uint32_t)accw[j + kM] + lo1[r] + (i1 << 16));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (dbg_acc) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) dbg_acc[(size_t)item * 2 * kN + 128 * r + tid] = acc[128 * r + tid];
+    }
+    // K4: sample extract
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = tid; j <= kN; j += 128)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    }
+}
+
+
+}  // namespace
+
+bool supported(const Params& p) { return p.N == kN && p.k == 1 && p.l == 3 && p.Bgbit == 7 && p.n <= 4096; }
+
+size_t spectrum_elems(const Params& p) { return (size_t)p.n * p.kpl() * 4 * kM; }
+
+size_t lds_bytes(const Params& p) {
+    return (size_t)2 * kTile * sizeof(double2) + (size_t)2 * kN * 4 + (((size_t)p.n * 2 + 15) & ~(size_t)15);
+}
+
+void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, hipStream_t stream) {
+    const size_t npoly = (size_t)p.n * p.kpl() * 2;
+    hipLaunchKernelGGL(k_bk_to_spectrum_w64, dim3((unsigned)npoly), dim3(64), 0, stream, d_bk_raw, d_bkf);
+}
+
+void launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDesc& W, int64_t items, Torus32* ext,
+            int32_t steps, Torus32* dbg_acc, hipStream_t stream) {
+    (void)p;
+    static const int variant = getenv("IEACHE_BR_VARIANT") ? atoi(getenv("IEACHE_BR_VARIANT")) : 0;
+    const dim3 grid((unsigned)items), blk(128);
+    const size_t lds = lds_bytes(p);
+    switch (variant) {
+        case 1: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, true>), grid, blk, lds, stream, K, d_bkf, W, ext, steps, dbg_acc); break;
+        case 2: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, W, ext, steps, dbg_acc); break;
+        case 3: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, false>), grid, blk, lds, stream, K, d_bkf, W, ext, steps, dbg_acc); break;
+        default: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, W, ext, steps, dbg_acc); break;
+    }
+}
+
+}  // namespace w64
+}  // namespace ieache

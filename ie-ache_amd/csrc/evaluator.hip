@@ -17,6 +17,9 @@
 // definition (and the CPU oracle) bit for bit, whatever the FFT schedule.
 #include "evaluator.h"
 
+#include "blind_rotate_w64.h"
+#include "device_common.h"
+
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
@@ -35,109 +38,7 @@ namespace {
 
 constexpr int kThreads = 256;
 
-struct DevKeys {
-    int32_t n, N, M, logM, l, Bgbit, kpl, ks_t, ks_basebit, ks_base, stride;
-    uint32_t dec_offset;
-    const double2* bkf;   // [n][kpl][2][2 limbs][M], bit-reversed spectrum order
-    const int32_t* ksk;   // [N][t][base][stride]
-    const double2* twist; // exp(i*pi*j/N), j < M
-    const double2* wtab;  // exp(-2*pi*i*j/M), j < M/2
-};
-
-// Where the gate instances of one launch live.
-struct WorkDesc {
-    const DevGate* gates;  // circuit mode when non-null
-    int32_t g0, ng;
-    Torus32* store;
-    int32_t n_slots;
-    const Torus32* flat_a;  // flat mode: rows [item]
-    const Torus32* flat_b;
-    Torus32* flat_out;
-    int32_t flat_type;
-    int64_t item0;
-};
-
-struct GateInst {
-    const Torus32* a;
-    const Torus32* b;
-    Torus32* out;
-    int32_t sa, sb;  // signed multipliers (0 = operand is the constant, handled via cst)
-    uint32_t cst;
-};
-
-__device__ __forceinline__ void gate_coeffs(int32_t type, int32_t& k, uint32_t& cst) {
-    // boot-gates.cpp: AND (0,-1/8)+ca+cb ; XOR (0,1/4)+2(ca+cb) ; OR (0,1/8)+ca+cb ; NAND (0,1/8)-ca-cb
-    switch (type) {
-        case GATE_AND: k = 1; cst = 0xE0000000u; break;
-        case GATE_XOR: k = 2; cst = 0x40000000u; break;
-        case GATE_OR: k = 1; cst = 0x20000000u; break;
-        default: k = -1; cst = 0x20000000u; break;  // NAND
-    }
-}
-
-__device__ __forceinline__ GateInst resolve(const WorkDesc& W, int64_t item, int32_t stride) {
-    GateInst g;
-    int32_t type, k;
-    if (W.gates) {
-        const int64_t b = item / W.ng;
-        const DevGate d = W.gates[W.g0 + (int32_t)(item % W.ng)];
-        Torus32* base = W.store + (size_t)b * W.n_slots * stride;
-        type = d.type;
-        gate_coeffs(type, k, g.cst);
-        g.a = d.a_slot >= 0 ? base + (size_t)d.a_slot * stride : nullptr;
-        g.b = d.b_slot >= 0 ? base + (size_t)d.b_slot * stride : nullptr;
-        g.out = base + (size_t)d.out_slot * stride;
-        g.sa = d.a_neg ? -k : k;
-        g.sb = d.b_neg ? -k : k;
-        // a constant operand is (0, -1/8): only its b term contributes
-        if (!g.a) g.cst += (uint32_t)g.sa * 0xE0000000u;
-        if (!g.b) g.cst += (uint32_t)g.sb * 0xE0000000u;
-    } else {
-        type = W.flat_type;
-        gate_coeffs(type, k, g.cst);
-        g.a = W.flat_a + (size_t)item * stride;
-        g.b = W.flat_b ? W.flat_b + (size_t)item * stride : nullptr;
-        g.out = W.flat_out + (size_t)item * stride;
-        g.sa = k;
-        g.sb = k;
-        if (type < 0) {  // raw bootstrap of the row in flat_a (debug hook)
-            g.sa = 1;
-            g.sb = 0;
-            g.cst = 0;
-            g.b = nullptr;
-        }
-    }
-    return g;
-}
-
-__device__ __forceinline__ uint32_t combined_coef(const GateInst& g, int32_t i, int32_t n) {
-    uint32_t v = 0;
-    if (g.a) v += (uint32_t)g.sa * (uint32_t)g.a[i];
-    if (g.b) v += (uint32_t)g.sb * (uint32_t)g.b[i];
-    if (i == n) v += g.cst;
-    return v;
-}
-
-// libtfhe modSwitchFromTorus32(phase, 2N) for power-of-two N: (phase + 2^(31-log2(2N))) >> (32-log2(2N))
-__device__ __forceinline__ int32_t modswitch2N(uint32_t phase, int32_t log2N2) {
-    return (int32_t)((phase + (1u << (31 - log2N2))) >> (32 - log2N2));
-}
-
-// coefficient i of X^a * p  (mod X^N+1), a in [0,2N)
-__device__ __forceinline__ int32_t rot_coef(const int32_t* p, int32_t i, int32_t a, int32_t N) {
-    const int32_t idx = (i - a) & (2 * N - 1);
-    return idx < N ? p[idx] : (int32_t)(0u - (uint32_t)p[idx - N]);
-}
-
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ double2 cmul_conj(double2 a, double2 b) {  // a * conj(b)
-    return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-}
-__device__ __forceinline__ double2 cfma(double2 a, double2 b, double2 c) {  // a*b + c
-    return make_double2(fma(a.x, b.x, fma(-a.y, b.y, c.x)), fma(a.x, b.y, fma(a.y, b.x, c.y)));
-}
+using namespace dev;
 
 // In-LDS radix-2 transforms over `npoly` polynomials of M complex points.
 // Forward: DIF, natural in -> bit-reversed out.  Inverse: DIT, bit-reversed in
@@ -350,6 +251,90 @@ __global__ __launch_bounds__(kThreads) void k_keyswitch_generic(DevKeys K, WorkD
     if (q2 < stride) out[q2] = q2 <= n ? (int32_t)(r2 + (q2 == n ? bprime : 0u)) : 0;
 }
 
+// ---- K5, vectorised: one 512-thread workgroup per gate instance ----
+// The non-zero digits are compacted into a row list; the 8 waves take list
+// entries round-robin, each wave subtracting whole 16-byte-per-lane row pieces
+// (NLD dwordx4 loads cover one padded KSK row), four rows in flight per wave;
+// the 8 partial sums meet in LDS.  Subtraction mod 2^32 commutes, so neither the
+// list order nor the split changes a single bit.
+// LDS: u [N+4] | list [N*t] | part [8][stride]
+constexpr int kKsThreads = 512;
+template <int NLD>
+__global__ __launch_bounds__(kKsThreads) void k_keyswitch_vec(DevKeys K, WorkDesc W, const Torus32* ext,
+                                                              Torus32* flat_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int32_t N = K.N, n = K.n, t = K.ks_t, basebit = K.ks_basebit, stride = K.stride;
+    int32_t* u = reinterpret_cast<int32_t*>(smem);
+    uint32_t* list = reinterpret_cast<uint32_t*>(u + N + 4);
+    int4* part = reinterpret_cast<int4*>(list + (size_t)N * t);
+    __shared__ uint32_t s_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t item = (int64_t)blockIdx.x;
+    const Torus32* src = ext + (size_t)item * (N + 4);
+    if (tid == 0) s_count = 0;
+    for (int32_t j = tid; j <= N; j += kKsThreads) u[j] = src[j];
+    __syncthreads();
+    const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+    const uint32_t mask = (1u << basebit) - 1;
+    for (int32_t idx = tid; idx < N * t; idx += kKsThreads) {
+        const int32_t i = idx / t, j = idx - i * t;
+        const uint32_t d = (((uint32_t)u[i] + prec_offset) >> (32 - (j + 1) * basebit)) & mask;
+        if (d) list[atomicAdd(&s_count, 1u)] = ((uint32_t)idx << basebit) + d;  // row index [i][j][d]
+    }
+    __syncthreads();
+    const uint32_t cnt = s_count;
+    const int32_t nvec = stride >> 2;
+    int4 acc[NLD];
+#pragma unroll
+    for (int v = 0; v < NLD; v++) acc[v] = make_int4(0, 0, 0, 0);
+    const int4* kbase = reinterpret_cast<const int4*>(K.ksk);
+    uint32_t e = wave;
+    for (; e + 24 < cnt; e += 32) {  // four rows (e, e+8, e+16, e+24) in flight
+        int4 r[4][NLD];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int4* row = kbase + (size_t)list[e + 8 * q] * nvec;
+#pragma unroll
+            for (int v = 0; v < NLD; v++)
+                r[q][v] = (lane + 64 * v < nvec) ? row[lane + 64 * v] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int v = 0; v < NLD; v++) {
+                acc[v].x -= r[q][v].x;
+                acc[v].y -= r[q][v].y;
+                acc[v].z -= r[q][v].z;
+                acc[v].w -= r[q][v].w;
+            }
+    }
+    for (; e < cnt; e += 8) {
+        const int4* row = kbase + (size_t)list[e] * nvec;
+#pragma unroll
+        for (int v = 0; v < NLD; v++)
+            if (lane + 64 * v < nvec) {
+                const int4 rr = row[lane + 64 * v];
+                acc[v].x -= rr.x;
+                acc[v].y -= rr.y;
+                acc[v].z -= rr.z;
+                acc[v].w -= rr.w;
+            }
+    }
+#pragma unroll
+    for (int v = 0; v < NLD; v++)
+        if (lane + 64 * v < nvec) part[(size_t)wave * nvec + lane + 64 * v] = acc[v];
+    __syncthreads();
+    Torus32* out = flat_out ? flat_out + (size_t)item * stride : resolve(W, W.item0 + item, stride).out;
+    const int32_t* parti = reinterpret_cast<const int32_t*>(part);
+    for (int32_t q = tid; q < stride; q += kKsThreads) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) v += (uint32_t)parti[(size_t)w * stride + q];
+        if (q == n) v += (uint32_t)u[N];
+        out[q] = q <= n ? (int32_t)v : 0;
+    }
+}
+
 // outputs of a circuit: out[b][o] = +-store[b][slot] or the constant
 __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus32* store, int32_t n_slots,
                                  Torus32* out, int64_t batch, int32_t stride, int32_t n) {
@@ -374,6 +359,9 @@ __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus3
 struct Evaluator::Impl {
     DevKeys K{};
     double2* bkf = nullptr;
+    double2* bkf_w64 = nullptr;  // spectrum in the wave-per-gate kernel's layout
+    bool use_w64 = false;
+    bool force_generic_ks = false;
     int32_t* ksk = nullptr;
     double2* twist = nullptr;
     double2* wtab = nullptr;
@@ -386,7 +374,8 @@ struct Evaluator::Impl {
     size_t d_gates_cap = 0;
     OutRef* d_outs = nullptr;
     size_t d_outs_cap = 0;
-    size_t br_lds = 0, ks_lds = 0;
+    size_t br_lds = 0, ks_lds = 0, ksv_lds = 0;
+    int ks_nld = 0;  // dwordx4 loads per KSK row per wave; 0 = use the scalar kernel
 };
 
 Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(new Impl) {
@@ -430,6 +419,16 @@ Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(n
         throw std::invalid_argument("parameter set exceeds the 160 KiB LDS of a CU");
     HIP_CHECK(hipFuncSetAttribute((const void*)k_blind_rotate_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d_->br_lds));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_keyswitch_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d_->ks_lds));
+    {
+        const int nvec = K.stride / 4, nld = (nvec + 63) / 64;
+        d_->ksv_lds = (size_t)(p.N + 4) * 4 + (size_t)p.N * p.ks_t * 4 + (size_t)8 * K.stride * 4;
+        if (nld <= 4 && d_->ksv_lds <= 160 * 1024) {
+            d_->ks_nld = nld;
+            const void* f = nld == 1 ? (const void*)k_keyswitch_vec<1> : nld == 2 ? (const void*)k_keyswitch_vec<2>
+                          : nld == 3 ? (const void*)k_keyswitch_vec<3> : (const void*)k_keyswitch_vec<4>;
+            HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d_->ksv_lds));
+        }
+    }
 }
 
 Evaluator::~Evaluator() {
@@ -437,6 +436,7 @@ Evaluator::~Evaluator() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     (void)hipFree(d_->bkf);
+    (void)hipFree(d_->bkf_w64);
     (void)hipFree(d_->ksk);
     (void)hipFree(d_->twist);
     (void)hipFree(d_->wtab);
@@ -453,7 +453,9 @@ void Evaluator::set_chunk(size_t items) {
     d_->chunk = items;
 }
 
-std::string Evaluator::kernel_variant() const { return "generic-radix2"; }
+std::string Evaluator::kernel_variant() const {
+    return (w64::supported(p_) && !force_generic_) ? "w2x64-radix8-registers" : "generic-radix2";
+}
 
 void Evaluator::load_keys_host(const Torus32* bk, const Torus32* ksk) {
     HIP_CHECK(hipSetDevice(device_));
@@ -485,6 +487,11 @@ void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
     hipLaunchKernelGGL(k_bk_to_spectrum, dim3((unsigned)npoly), dim3(kThreads), 2 * K.M * sizeof(double2), stream_, K,
                        d_bk, d_->bkf);
     HIP_CHECK(hipGetLastError());
+    if (w64::supported(p_)) {
+        if (!d_->bkf_w64) HIP_CHECK(hipMalloc(&d_->bkf_w64, w64::spectrum_elems(p_) * sizeof(double2)));
+        w64::prepare_spectrum(p_, d_bk, d_->bkf_w64, stream_);
+        HIP_CHECK(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_pad_rows, dim3(2048), dim3(256), 0, stream_, d_ksk, d_->ksk, (int64_t)ks_rows, p_.n + 1,
                        K.stride);
     HIP_CHECK(hipGetLastError());
@@ -521,7 +528,31 @@ struct Timer {
 }  // namespace
 
 // Runs `items` gate instances described by W (item0 is advanced per chunk).
-static void run_items(Evaluator::Impl* d, hipStream_t stream, WorkDesc W, int64_t items,
+static void launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt,
+                                Torus32* ext, int32_t steps, Torus32* dbg_acc) {
+    if (d->use_w64)
+        w64::launch(p, d->K, d->bkf_w64, w, cnt, ext, steps, dbg_acc, stream);
+    else
+        hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,
+                           steps, dbg_acc);
+}
+
+static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt, const Torus32* ext,
+                             Torus32* flat_out, bool force_generic) {
+    const DevKeys& K = d->K;
+    const dim3 grid((unsigned)cnt), blk(kKsThreads);
+    const int nld = force_generic ? 0 : d->ks_nld;
+    switch (nld) {
+        case 1: hipLaunchKernelGGL(k_keyswitch_vec<1>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
+        case 2: hipLaunchKernelGGL(k_keyswitch_vec<2>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
+        case 3: hipLaunchKernelGGL(k_keyswitch_vec<3>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
+        case 4: hipLaunchKernelGGL(k_keyswitch_vec<4>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
+        default:
+            hipLaunchKernelGGL(k_keyswitch_generic, grid, dim3(kThreads), d->ks_lds, stream, K, w, ext, flat_out);
+    }
+}
+
+static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, WorkDesc W, int64_t items,
                       Timer& tbr, Timer& tks, EvalStats* stats) {
     const DevKeys& K = d->K;
     const size_t chunk = d->chunk;
@@ -535,13 +566,11 @@ static void run_items(Evaluator::Impl* d, hipStream_t stream, WorkDesc W, int64_
         WorkDesc w = W;
         w.item0 = W.item0 + done;
         tbr.mark();
-        hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, K, w, d->ext,
-                           -1, (Torus32*)nullptr);
+        launch_blind_rotate(p, d, stream, w, cnt, d->ext, -1, nullptr);
         tbr.mark();
         HIP_CHECK(hipGetLastError());
         tks.mark();
-        hipLaunchKernelGGL(k_keyswitch_generic, dim3((unsigned)cnt), dim3(kThreads), d->ks_lds, stream, K, w, d->ext,
-                           (Torus32*)nullptr);
+        launch_keyswitch(d, stream, w, cnt, d->ext, nullptr, d->force_generic_ks);
         tks.mark();
         HIP_CHECK(hipGetLastError());
         if (stats) {
@@ -557,6 +586,8 @@ void Evaluator::gates_device(int32_t type, size_t count, const Torus32* d_a, con
     if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
     HIP_CHECK(hipSetDevice(device_));
     if (count == 0) return;
+    d_->use_w64 = w64::supported(p_) && !force_generic_;
+    d_->force_generic_ks = force_generic_;
     Timer tall(stats != nullptr, stream_), tbr(stats != nullptr, stream_), tks(stats != nullptr, stream_);
     WorkDesc W{};
     W.gates = nullptr;
@@ -566,7 +597,7 @@ void Evaluator::gates_device(int32_t type, size_t count, const Torus32* d_a, con
     W.flat_type = type;
     W.item0 = 0;
     tall.mark();
-    run_items(d_, stream_, W, (int64_t)count, tbr, tks, stats);
+    run_items(p_, d_, stream_, W, (int64_t)count, tbr, tks, stats);
     tall.mark();
     HIP_CHECK(hipStreamSynchronize(stream_));
     if (stats) {
@@ -582,6 +613,8 @@ void Evaluator::eval_circuit_device(const Circuit& c, size_t batch, const Torus3
     if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
     HIP_CHECK(hipSetDevice(device_));
     if (batch == 0) return;
+    d_->use_w64 = w64::supported(p_) && !force_generic_;
+    d_->force_generic_ks = force_generic_;
     const int32_t stride = d_->K.stride;
     const size_t row_bytes = (size_t)stride * 4;
     const size_t need = batch * (size_t)c.n_slots * row_bytes;
@@ -619,7 +652,7 @@ void Evaluator::eval_circuit_device(const Circuit& c, size_t batch, const Torus3
         W.store = d_->store;
         W.n_slots = c.n_slots;
         W.item0 = 0;
-        run_items(d_, stream_, W, (int64_t)W.ng * (int64_t)batch, tbr, tks, stats);
+        run_items(p_, d_, stream_, W, (int64_t)W.ng * (int64_t)batch, tbr, tks, stats);
         if (stats) stats->levels++;
     }
     const int32_t n_out = (int32_t)c.outputs.size();
@@ -643,8 +676,9 @@ void Evaluator::debug_blind_rotate(size_t count, const Torus32* d_x, Torus32* d_
     W.flat_b = nullptr;
     W.flat_out = nullptr;
     W.flat_type = -1;
-    hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)count), dim3(kThreads), d_->br_lds, stream_, d_->K, W,
-                       (Torus32*)nullptr, steps, d_acc);
+    d_->use_w64 = w64::supported(p_) && !force_generic_;
+    d_->force_generic_ks = force_generic_;
+    launch_blind_rotate(p_, d_, stream_, W, (int64_t)count, nullptr, steps, d_acc);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -658,8 +692,7 @@ void Evaluator::debug_keyswitch(size_t count, const Torus32* d_u, Torus32* d_out
     HIP_CHECK(hipMemcpy2DAsync(tmp, (size_t)(p_.N + 4) * 4, d_u, (size_t)(p_.N + 1) * 4, (size_t)(p_.N + 1) * 4, count,
                                hipMemcpyDeviceToDevice, stream_));
     WorkDesc W{};
-    hipLaunchKernelGGL(k_keyswitch_generic, dim3((unsigned)count), dim3(kThreads), d_->ks_lds, stream_, d_->K, W, tmp,
-                       d_out);
+    launch_keyswitch(d_, stream_, W, (int64_t)count, tmp, d_out, force_generic_);
     hipError_t e = hipGetLastError();
     (void)hipStreamSynchronize(stream_);
     (void)hipFree(tmp);
