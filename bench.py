@@ -174,10 +174,15 @@ def main():
         gates_total = info.bootstraps * batch * args.steps * world
         value = gates_total / elapsed
         per_gate = algorithmic_bytes_per_gate(p)
-        # dominant kernel: blind rotation.  Its launches each process (gate instances / launches) gates.
+        # dominant kernel: blind rotation (k_blind_rotate_*).  One launch advances `gates_per_launch`
+        # gates by `steps_per_launch` of their n CMux steps, i.e. processes that fraction of each gate's
+        # algorithmic bytes; achieved = algorithmic bytes per launch / average launch duration (HIP
+        # events on the evaluator's stream bracket the launches of each chunk).
         br_avg_ms = stats.blind_rotate_ms / max(1, stats.blind_rotate_launches)
-        gates_per_launch = stats.bootstraps / max(1, stats.blind_rotate_launches)
-        achieved = per_gate * gates_per_launch / (br_avg_ms * 1e-3) / 1e9 if br_avg_ms > 0 else 0.0
+        gates_per_launch = stats.bootstraps / max(1, stats.chunks)
+        launches_per_gate = stats.blind_rotate_launches / max(1, stats.chunks)
+        bytes_per_launch = per_gate * gates_per_launch / max(1.0, launches_per_gate)
+        achieved = bytes_per_launch / (br_avg_ms * 1e-3) / 1e9 if br_avg_ms > 0 else 0.0
         out = {
             "metric": "bootstrapped gate ops/sec",
             "value": value,
@@ -198,7 +203,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_blind_rotate", "avg_launch_ms": br_avg_ms, "gates_per_launch": gates_per_launch,
-                         "algorithmic_bytes_per_gate": per_gate,
+                         "cmux_steps_per_launch": p.n / max(1.0, launches_per_gate),
+                         "algorithmic_bytes_per_gate": per_gate, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "blind_rotate_share": stats.blind_rotate_ms / max(1e-9, stats.total_ms),
                          "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms)},
         }

@@ -12,9 +12,14 @@ size_t spectrum_elems(const Params& p);
 size_t lds_bytes(const Params& p);
 // raw BK [n][2l][2][N] int32 (device) -> two-limb spectrum [n][2l][4][8][64] double2
 void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, hipStream_t stream);
-// K0..K4 for `items` gate instances; ext rows of N+4 int32 (may be null), dbg_acc [items][2][N] (may be null)
-void launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const dev::WorkDesc& W, int64_t items,
-            Torus32* ext, int32_t steps, Torus32* dbg_acc, hipStream_t stream);
+// bytes of blind-rotation state (accumulator + rotation amounts) one gate instance keeps in HBM between slices
+size_t state_bytes_per_item(const Params& p);
+// K0..K4 for `items` gate instances: prologue, then the CMux steps in slices of S steps per launch
+// (IEACHE_BR_SLICE, default 16).  state: items * state_bytes_per_item() bytes of scratch.
+// ext rows of N+4 int32 (may be null), dbg_acc [items][2][N] (may be null; when set, pass ext = null).
+// Returns the number of k_blind_rotate_w2 launches issued.
+int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const dev::WorkDesc& W, int64_t items,
+           void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, hipStream_t stream);
 
 }  // namespace w64
 }  // namespace ieache

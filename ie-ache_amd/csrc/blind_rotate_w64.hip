@@ -17,6 +17,7 @@
 //     per-lane roots of unity instead of tables.
 #include "blind_rotate_w64.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace ieache {
@@ -81,6 +82,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// diagnostic cycle stamp (s_memtime), fenced so segments are not reordered across it
+__device__ __forceinline__ unsigned long long stamp() {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
 }
 
 template <bool WSYNC>
@@ -221,29 +231,17 @@ __global__ __launch_bounds__(64) void k_bk_to_spectrum_w64(const Torus32* bk_raw
     }
 }
 
-// ---- K0..K4: one 128-thread workgroup (two waves) per gate instance ----
-// Wave w decomposes accumulator polynomial w (its 3 digit rows -> 3 forward
-// transforms), owns the spectrum-domain sums of OUTPUT polynomial w (both
-// limbs) and inverse-transforms them.  Each forward spectrum is handed to the
-// partner wave through the producing wave's own (then idle) transpose tile.
-// dynamic LDS: sT [2][kTile] double2 | acc [2][1024] int32 | bara [n] u16
-template <int L, int BGBIT, bool PREFETCH, bool WSYNC>
-__global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf, WorkDesc W,
-                                                           Torus32* ext, int32_t steps, Torus32* dbg_acc) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    double2* sT_all = reinterpret_cast<double2*>(smem);
-    int32_t* acc = reinterpret_cast<int32_t*>(sT_all + 2 * kTile);
-    uint16_t* bara = reinterpret_cast<uint16_t*>(acc + 2 * kN);
+// ---- K0..K2: gate pre-combination, mod-switch, test-vector init ----
+// One 128-thread workgroup per gate instance.  Writes the rotation amounts
+// bara[n] (u16, row stride nb) and the initial accumulator [2][1024] to the
+// blind-rotation state in HBM, from where the sliced kernel below picks up.
+__global__ __launch_bounds__(128) void k_br_prologue(DevKeys K, WorkDesc W, uint16_t* st_bara, int32_t nb, int32_t* st_acc) {
     __shared__ int32_t s_barb;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double2* sT = sT_all + wave * kTile;
-    const double2* sTp = sT_all + (wave ^ 1) * kTile;
+    const int tid = threadIdx.x;
     const int32_t n = K.n;
     const int64_t item = (int64_t)blockIdx.x;
     const GateInst g = resolve(W, W.item0 + item, K.stride);
-    const LaneRoots R = make_roots(lane);
-
-    // K0 + K1: gate pre-combination and mod-switch to Z_2N
+    uint16_t* bara = st_bara + (size_t)item * nb;
     for (int32_t i = tid; i <= n; i += 128) {
         const int32_t bar = modswitch2N(combined_coef(g, i, n), 11);
         if (i < n)
@@ -252,15 +250,49 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
             s_barb = bar;
     }
     __syncthreads();
-    // K2: acc = (0, X^{2N-barb} * (mu,...,mu))
-    {
-        const int32_t a0 = (2 * kN - s_barb) & (2 * kN - 1);
+    // acc = (0, X^{2N-barb} * (mu,...,mu))
+    const int32_t a0 = (2 * kN - s_barb) & (2 * kN - 1);
+    int32_t* acc = st_acc + (size_t)item * 2 * kN;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int32_t j = 128 * r + tid;
-            acc[j] = 0;
-            acc[kN + j] = ((j - a0) & (2 * kN - 1)) < kN ? kMU : -kMU;
-        }
+    for (int r = 0; r < 8; r++) {
+        const int32_t j = 128 * r + tid;
+        acc[j] = 0;
+        acc[kN + j] = ((j - a0) & (2 * kN - 1)) < kN ? kMU : -kMU;
+    }
+}
+
+// ---- K3 (+K4): CMux steps [i0, i1) for every gate instance of the launch ----
+// One 128-thread workgroup (two waves) per gate instance.  The step index is the
+// OUTER loop of the evaluator: a chunk of gates is advanced S steps per launch, so
+// all resident workgroups read the same S blocks BK_i0..BK_i1 while those are hot
+// in the XCD's L2 (with the whole blind rotation in one launch, workgroups drift
+// apart in i and each streams its own BK_i from Infinity Cache/HBM: measured 51 MB
+// of fetch per gate).  The accumulator lives in HBM between launches (8 KB per gate).
+// Wave w decomposes accumulator polynomial w (its 3 digit rows -> 3 forward
+// transforms), owns the spectrum-domain sums of OUTPUT polynomial w (both
+// limbs) and inverse-transforms them.  Each forward spectrum is handed to the
+// partner wave through the producing wave's own (then idle) transpose tile.
+// dynamic LDS: sT [2][kTile] double2 | acc [2][1024] int32
+template <int L, int BGBIT, bool DIAG, bool WSYNC>
+__global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf,
+                                                           const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                           int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
+                                                           unsigned long long* diag) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* sT_all = reinterpret_cast<double2*>(smem);
+    int32_t* acc = reinterpret_cast<int32_t*>(sT_all + 2 * kTile);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double2* sT = sT_all + wave * kTile;
+    const double2* sTp = sT_all + (wave ^ 1) * kTile;
+    const int64_t item = (int64_t)blockIdx.x;
+    const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    const LaneRoots R = make_roots(lane);
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[128 * r + tid] = src[128 * r + tid];
     }
     __syncthreads();
 
@@ -268,13 +300,23 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    const int32_t nsteps = steps < 0 ? n : steps;
     constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: (x + magic) carries round(x) in its low mantissa bits
     int32_t* accw = acc + wave * kN;  // the polynomial this wave decomposes and updates
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    if (DIAG) tlast = stamp();
+#define IEACHE_STAMP(idx)                   \
+    if (DIAG) {                             \
+        const unsigned long long t_ = stamp(); \
+        tsum[idx] += t_ - tlast;            \
+        tlast = t_;                         \
+    }
 
+    // this slice's rotation amounts: one per lane, fetched once, then read with readlane
+    // (a dependent global load at the head of every step costs ~2-3k cycles)
+    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
 #pragma unroll 1
-    for (int32_t i = 0; i < nsteps; i++) {
-        const int32_t a = bara[i];
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
         if (a == 0) continue;  // workgroup-uniform; exact arithmetic makes the step a no-op
         // BK_i rows [2L][4][8][64]; this wave reads outputs o = 2*wave, 2*wave+1 of every row
         const double2* __restrict__ bki = bkf + (size_t)i * (2 * L * 4 * kM) + (size_t)(2 * wave) * kM + lane;
@@ -291,6 +333,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
             v0[r] = (uint32_t)rot_coef(accw, j, a, kN) - (uint32_t)accw[j] + dec_offset;
             v1[r] = (uint32_t)rot_coef(accw, j + kM, a, kN) - (uint32_t)accw[j + kM] + dec_offset;
         }
+        IEACHE_STAMP(0)
 #pragma unroll 1
         for (int q = 0; q < L; q++) {
             const int sh = 32 - (q + 1) * BGBIT;
@@ -303,23 +346,15 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
                 const int32_t e1 = (int32_t)((v1[r] >> sh) & maskBg) - (int32_t)halfBg;
                 x[r] = cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
-            // BK for our own row, first limb: optionally requested before the transform so
-            // that the L2 round trip overlaps ~1500 cycles of butterflies
             double2 bpre[8];
-            if (PREFETCH) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) bpre[k] = bown[k * 64];
-                __builtin_amdgcn_sched_barrier(0);
-            }
             fft512_forward<WSYNC>(x, sT, lane, R);
+            IEACHE_STAMP(1)
             // hand the spectrum to the partner wave through our own (now idle) tile
 #pragma unroll
             for (int k = 0; k < 8; k++) sT[k * 64 + lane] = x[k];
             // own row: s[o] += x * B[own row][2*wave + o]
-            if (!PREFETCH) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) bpre[k] = bown[k * 64];
-            }
+            for (int k = 0; k < 8; k++) bpre[k] = bown[k * 64];
             {
                 double2 b[8];
 #pragma unroll
@@ -333,7 +368,9 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
                     s[1][k] = make_double2(fma(x[k].x, b[k].x, fma(-x[k].y, b[k].y, s[1][k].x)),
                                            fma(x[k].x, b[k].y, fma(x[k].y, b[k].x, s[1][k].y)));
             }
+            IEACHE_STAMP(2)
             __syncthreads();
+            IEACHE_STAMP(3)
             // partner's row
 #pragma unroll
             for (int k = 0; k < 8; k++) x[k] = sTp[k * 64 + lane];
@@ -347,7 +384,9 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
                     s[o][k] = make_double2(fma(x[k].x, b[k].x, fma(-x[k].y, b[k].y, s[o][k].x)),
                                            fma(x[k].x, b[k].y, fma(x[k].y, b[k].x, s[o][k].y)));
             }
+            IEACHE_STAMP(4)
             __syncthreads();  // partner has read our tile before the next transform reuses it
+            IEACHE_STAMP(5)
         }
         // back to coefficients, round, recombine the two limbs, accumulate into polynomial `wave`
         uint32_t lo0[8], lo1[8];
@@ -369,20 +408,27 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
                 }
             }
         }
+        IEACHE_STAMP(6)
         __syncthreads();
+        IEACHE_STAMP(7)
     }
-    if (dbg_acc) {
+#undef IEACHE_STAMP
+    if (DIAG && diag && lane == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) dbg_acc[(size_t)item * 2 * kN + 128 * r + tid] = acc[128 * r + tid];
+        for (int t = 0; t < 8; t++) atomicAdd(&diag[wave * 8 + t], tsum[t]);
     }
-    // K4: sample extract
     if (ext) {
+        // K4: sample extract after the last slice
         Torus32* u = ext + (size_t)item * (kN + 4);
         for (int32_t j = tid; j <= kN; j += 128)
             u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[128 * r + tid] = src[128 * r + tid];
     }
 }
-
 
 }  // namespace
 
@@ -391,26 +437,82 @@ bool supported(const Params& p) { return p.N == kN && p.k == 1 && p.l == 3 && p.
 size_t spectrum_elems(const Params& p) { return (size_t)p.n * p.kpl() * 4 * kM; }
 
 size_t lds_bytes(const Params& p) {
-    return (size_t)2 * kTile * sizeof(double2) + (size_t)2 * kN * 4 + (((size_t)p.n * 2 + 15) & ~(size_t)15);
+    (void)p;
+    return (size_t)2 * kTile * sizeof(double2) + (size_t)2 * kN * 4;
 }
+
+int32_t bara_stride(const Params& p) { return (p.n + 7) & ~7; }
+
+size_t state_bytes_per_item(const Params& p) { return (size_t)bara_stride(p) * 2 + (size_t)2 * kN * 4; }
 
 void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, hipStream_t stream) {
     const size_t npoly = (size_t)p.n * p.kpl() * 2;
     hipLaunchKernelGGL(k_bk_to_spectrum_w64, dim3((unsigned)npoly), dim3(64), 0, stream, d_bk_raw, d_bkf);
 }
 
-void launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDesc& W, int64_t items, Torus32* ext,
-            int32_t steps, Torus32* dbg_acc, hipStream_t stream) {
-    (void)p;
+// diagnostic build (IEACHE_BR_VARIANT=1): per-segment s_memtime sums, printed per launch() call
+static unsigned long long* diag_buf() {
+    static unsigned long long* p = nullptr;
+    if (!p) {
+        (void)hipMalloc(&p, 16 * sizeof(unsigned long long));
+        (void)hipMemset(p, 0, 16 * sizeof(unsigned long long));
+    }
+    return p;
+}
+static void diag_report(hipStream_t stream, int64_t items, int32_t nsteps) {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h, diag_buf(), sizeof h, hipMemcpyDeviceToHost);
+    (void)hipMemset(diag_buf(), 0, sizeof h);
+    static const char* names[8] = {"decompose", "build+fwdFFT(x3)", "tile+ownBK+MAC(x3)", "barrier1(x3)", "partner+BK+MAC(x3)",
+                                   "barrier2(x3)", "invFFT x2+update", "end barrier"};
+    const double denom = (double)items * (nsteps > 0 ? nsteps : 1);
+    for (int w = 0; w < 2; w++) {
+        double tot = 0;
+        for (int t = 0; t < 8; t++) tot += (double)h[w * 8 + t];
+        fprintf(stderr, "[br-diag] wave %d: %.0f memtime ticks per step:", w, tot / denom);
+        for (int t = 0; t < 8; t++) fprintf(stderr, " %s=%.0f", names[t], (double)h[w * 8 + t] / denom);
+        fprintf(stderr, "\n");
+    }
+}
+
+int32_t default_slice() {
+    static const int32_t s = getenv("IEACHE_BR_SLICE") ? atoi(getenv("IEACHE_BR_SLICE")) : 16;
+    return s > 0 ? (s < 64 ? s : 64) : 16;  // <= 64: one rotation amount per lane
+}
+
+int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDesc& W, int64_t items, void* state,
+           Torus32* ext, int32_t steps, Torus32* dbg_acc, hipStream_t stream) {
+    int launches = 0;
     static const int variant = getenv("IEACHE_BR_VARIANT") ? atoi(getenv("IEACHE_BR_VARIANT")) : 0;
     const dim3 grid((unsigned)items), blk(128);
     const size_t lds = lds_bytes(p);
-    switch (variant) {
-        case 1: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, true>), grid, blk, lds, stream, K, d_bkf, W, ext, steps, dbg_acc); break;
-        case 2: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, W, ext, steps, dbg_acc); break;
-        case 3: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, false>), grid, blk, lds, stream, K, d_bkf, W, ext, steps, dbg_acc); break;
-        default: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, W, ext, steps, dbg_acc); break;
+    const int32_t nb = bara_stride(p);
+    // state block: [items][2][1024] int32 accumulators, then [items][nb] u16 rotation amounts
+    int32_t* st_acc = reinterpret_cast<int32_t*>(state);
+    uint16_t* st_bara = reinterpret_cast<uint16_t*>(st_acc + (size_t)items * 2 * kN);
+    hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
+    const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
+    const int32_t S = default_slice();
+    for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
+        const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
+        Torus32* e = (i1 == nsteps) ? ext : nullptr;  // the last slice extracts instead of storing the accumulator
+        launches++;
+        switch (variant) {
+            case 1: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
+            case 2: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
+            default: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
+        }
     }
+    if (variant == 1) diag_report(stream, items, nsteps);
+    if (nsteps == 0 && ext) {
+        // degenerate (steps == 0): extraction straight from the initial accumulator
+        hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext,
+                           (unsigned long long*)nullptr);
+    }
+    if (dbg_acc)
+        (void)hipMemcpyAsync(dbg_acc, st_acc, (size_t)items * 2 * kN * 4, hipMemcpyDeviceToDevice, stream);
+    return launches;
 }
 
 }  // namespace w64

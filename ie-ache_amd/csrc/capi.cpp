@@ -86,6 +86,7 @@ void to_stats(const EvalStats& s, ieache_stats* o) {
     o->keyswitch_launches = s.keyswitch_launches;
     o->bootstraps = s.bootstraps;
     o->levels = s.levels;
+    o->chunks = s.chunks;
 }
 const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits) {
     auto key = std::make_pair(kind, bits);

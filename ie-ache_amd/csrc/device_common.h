@@ -100,8 +100,11 @@ __device__ __forceinline__ int32_t modswitch2N(uint32_t phase, int32_t log2N2) {
 
 // coefficient i of X^a * p  (mod X^N+1), a in [0,2N)
 __device__ __forceinline__ int32_t rot_coef(const int32_t* p, int32_t i, int32_t a, int32_t N) {
+    // branch-free: one load plus a conditional negate (a ?: on two loads compiles to
+    // divergent branches with a full LDS wait inside each)
     const int32_t idx = (i - a) & (2 * N - 1);
-    return idx < N ? p[idx] : (int32_t)(0u - (uint32_t)p[idx - N]);
+    const uint32_t v = (uint32_t)p[idx & (N - 1)];
+    return (int32_t)((idx & N) ? 0u - v : v);
 }
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {

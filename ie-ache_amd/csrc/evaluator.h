@@ -18,8 +18,9 @@ struct EvalStats {
     double total_ms = 0;         // wall time of the call on the GPU timeline (events on the stream)
     double blind_rotate_ms = 0;  // sum over blind-rotation launches
     double keyswitch_ms = 0;     // sum over key-switch launches
-    int64_t blind_rotate_launches = 0;
+    int64_t blind_rotate_launches = 0;  // k_blind_rotate_* kernel launches (one per slice of CMux steps per chunk)
     int64_t keyswitch_launches = 0;
+    int64_t chunks = 0;  // (level, chunk) work units = key-switch launches
     int64_t bootstraps = 0;  // gate instances bootstrapped
     int64_t levels = 0;
 };

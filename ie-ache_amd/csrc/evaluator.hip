@@ -20,6 +20,7 @@
 #include "blind_rotate_w64.h"
 #include "device_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
@@ -366,6 +367,8 @@ struct Evaluator::Impl {
     double2* twist = nullptr;
     double2* wtab = nullptr;
     Torus32* ext = nullptr;
+    void* br_state = nullptr;  // sliced blind rotation: accumulators + rotation amounts
+    size_t br_state_items = 0;
     size_t chunk = 16384;
     size_t ext_items = 0;
     Torus32* store = nullptr;
@@ -441,6 +444,7 @@ Evaluator::~Evaluator() {
     (void)hipFree(d_->twist);
     (void)hipFree(d_->wtab);
     (void)hipFree(d_->ext);
+    (void)hipFree(d_->br_state);
     (void)hipFree(d_->store);
     (void)hipFree(d_->d_gates);
     (void)hipFree(d_->d_outs);
@@ -528,13 +532,22 @@ struct Timer {
 }  // namespace
 
 // Runs `items` gate instances described by W (item0 is advanced per chunk).
-static void launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt,
+static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt,
                                 Torus32* ext, int32_t steps, Torus32* dbg_acc) {
-    if (d->use_w64)
-        w64::launch(p, d->K, d->bkf_w64, w, cnt, ext, steps, dbg_acc, stream);
+    if (d->use_w64) {
+        if (d->br_state_items < (size_t)cnt) {
+            if (d->br_state) HIP_CHECK(hipFree(d->br_state));
+            d->br_state = nullptr;
+            const size_t items = std::max<size_t>((size_t)cnt, d->chunk);
+            HIP_CHECK(hipMalloc(&d->br_state, items * w64::state_bytes_per_item(p)));
+            d->br_state_items = items;
+        }
+        return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, stream);
+    }
     else
         hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,
                            steps, dbg_acc);
+    return 1;
 }
 
 static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt, const Torus32* ext,
@@ -566,7 +579,7 @@ static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, W
         WorkDesc w = W;
         w.item0 = W.item0 + done;
         tbr.mark();
-        launch_blind_rotate(p, d, stream, w, cnt, d->ext, -1, nullptr);
+        const int nbr = launch_blind_rotate(p, d, stream, w, cnt, d->ext, -1, nullptr);
         tbr.mark();
         HIP_CHECK(hipGetLastError());
         tks.mark();
@@ -574,8 +587,9 @@ static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, W
         tks.mark();
         HIP_CHECK(hipGetLastError());
         if (stats) {
-            stats->blind_rotate_launches++;
+            stats->blind_rotate_launches += nbr;
             stats->keyswitch_launches++;
+            stats->chunks++;
         }
     }
     if (stats) stats->bootstraps += items;

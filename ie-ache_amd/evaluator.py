@@ -49,7 +49,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("blind_rotate_ms", C.c_double), ("keyswitch_ms", C.c_double),
                 ("blind_rotate_launches", C.c_int64), ("keyswitch_launches", C.c_int64),
-                ("bootstraps", C.c_int64), ("levels", C.c_int64)]
+                ("bootstraps", C.c_int64), ("levels", C.c_int64), ("chunks", C.c_int64)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

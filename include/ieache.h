@@ -44,10 +44,11 @@ typedef struct ieache_stats {
     double total_ms;          /* GPU timeline of the call (HIP events on the evaluator's stream) */
     double blind_rotate_ms;   /* sum over blind-rotation launches */
     double keyswitch_ms;      /* sum over key-switch launches */
-    int64_t blind_rotate_launches;
+    int64_t blind_rotate_launches; /* blind-rotation kernel launches (one per slice of CMux steps per chunk) */
     int64_t keyswitch_launches;
     int64_t bootstraps;       /* bootsAND/bootsXOR-equivalent gate instances evaluated */
     int64_t levels;
+    int64_t chunks;           /* (level, chunk) work units */
 } ieache_stats;
 
 /* circuit kinds = the branches of main() in Cloud/cloud.c */
