@@ -183,6 +183,15 @@ def main():
         launches_per_gate = stats.blind_rotate_launches / max(1, stats.chunks)
         bytes_per_launch = per_gate * gates_per_launch / max(1.0, launches_per_gate)
         achieved = bytes_per_launch / (br_avg_ms * 1e-3) / 1e9 if br_avg_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel from PMC counters: collected offline (rocprofv3 cannot run
+        # inside this process) by scripts/pmc_passes.sh and committed in profiles/traffic.json
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(ctx.kernel_variant)
+            if tj:
+                traffic = tj["hbm_bytes_per_gate_step"] * gates_per_launch * (p.n / max(1.0, launches_per_gate))
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "bootstrapped gate ops/sec",
             "value": value,
@@ -201,7 +210,7 @@ def main():
                        "params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2", "parallelism": "batch-sharded x%d" % world,
                        "kernel": ctx.kernel_variant, "key_broadcast_s": round(t_bcast, 4)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_blind_rotate", "avg_launch_ms": br_avg_ms, "gates_per_launch": gates_per_launch,
                          "cmux_steps_per_launch": p.n / max(1.0, launches_per_gate),
                          "algorithmic_bytes_per_gate": per_gate, "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -15,11 +15,11 @@ void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, 
 // bytes of blind-rotation state (accumulator + rotation amounts) one gate instance keeps in HBM between slices
 size_t state_bytes_per_item(const Params& p);
 // K0..K4 for `items` gate instances: prologue, then the CMux steps in slices of S steps per launch
-// (IEACHE_BR_SLICE, default 16).  state: items * state_bytes_per_item() bytes of scratch.
+// (`slice`, 1..64; 0 = default 16 or IEACHE_BR_SLICE).  state: items * state_bytes_per_item() bytes of scratch.
 // ext rows of N+4 int32 (may be null), dbg_acc [items][2][N] (may be null; when set, pass ext = null).
 // Returns the number of k_blind_rotate_w2 launches issued.
 int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const dev::WorkDesc& W, int64_t items,
-           void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, hipStream_t stream);
+           void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, hipStream_t stream);
 
 }  // namespace w64
 }  // namespace ieache

@@ -482,7 +482,7 @@ int32_t default_slice() {
 }
 
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDesc& W, int64_t items, void* state,
-           Torus32* ext, int32_t steps, Torus32* dbg_acc, hipStream_t stream) {
+           Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, hipStream_t stream) {
     int launches = 0;
     static const int variant = getenv("IEACHE_BR_VARIANT") ? atoi(getenv("IEACHE_BR_VARIANT")) : 0;
     const dim3 grid((unsigned)items), blk(128);
@@ -493,7 +493,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
     uint16_t* st_bara = reinterpret_cast<uint16_t*>(st_acc + (size_t)items * 2 * kN);
     hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
-    const int32_t S = default_slice();
+    const int32_t S = (slice >= 1 && slice <= 64) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
         Torus32* e = (i1 == nsteps) ? ext : nullptr;  // the last slice extracts instead of storing the accumulator

@@ -203,6 +203,12 @@ int ieache_ctx_force_generic(ieache_ctx* ctx, int on) {
     return 0;
 }
 
+int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return fail(IEACHE_EINVAL, "null argument");
+    if (!ctx->eval->set_option(name, value)) return fail(IEACHE_EINVAL, std::string("unknown option or bad value: ") + name);
+    return 0;
+}
+
 const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx) {
     if (!ctx) return "";
     const_cast<ieache_ctx*>(ctx)->variant = ctx->eval->kernel_variant();

@@ -65,6 +65,10 @@ public:
     void set_force_generic(bool v) { force_generic_ = v; }
     // Maximum gate instances per launch (bounds the scratch buffers).
     void set_chunk(size_t items);
+    // Named tuning knobs: "chunk", "force_generic", "ks_batch_min" (gate instances from which the
+    // gate-batched key switch is used), "br_slice" (CMux steps per blind-rotation launch, 1..64).
+    // Returns false for an unknown name or a value out of range.
+    bool set_option(const std::string& name, int64_t value);
     std::string kernel_variant() const;
 
     struct Impl;  // device buffers; defined in evaluator.hip

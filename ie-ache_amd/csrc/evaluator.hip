@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <vector>
 
@@ -336,6 +337,113 @@ __global__ __launch_bounds__(kKsThreads) void k_keyswitch_vec(DevKeys K, WorkDes
     }
 }
 
+// ---- K5, gate-batched: one workgroup per G gate instances ----
+// The key-switch key does not fit the L2s (83 MB), so K5 is bound by how many KSK bytes
+// are fetched per gate.  Here a workgroup walks ALL (i, j) positions once, loads the
+// three candidate rows [i][j][1..3] and lets each of its G gates subtract the one its
+// digit selects: 3 x 2.5 KB x N x t / G bytes per gate instead of ~0.75 x 2.5 KB x N x t.
+// One wave per 64 int4 columns of a row (3 waves at n=630), each lane owning one column
+// for all G gates, so no partial sums cross waves.  The t digits of a'_i are packed into
+// one word per gate, pulled into SGPRs once per i; selection is scalar branching, and
+// subtraction mod 2^32 commutes, so the result is bit-identical to the other kernels.
+// LDS: dw [G][N] u16 | bprime [G]
+template <int G>
+__global__ __launch_bounds__(256) void k_keyswitch_batch(DevKeys K, WorkDesc W, const Torus32* ext, Torus32* flat_out,
+                                                         int64_t items) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int32_t N = K.N, n = K.n, t = K.ks_t, basebit = K.ks_basebit, stride = K.stride;
+    uint16_t* dw = reinterpret_cast<uint16_t*>(smem);
+    int32_t* bprime = reinterpret_cast<int32_t*>(dw + (size_t)G * N);
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int64_t item0 = (int64_t)blockIdx.x * G;
+    const int32_t gcount = (int32_t)(items - item0 < G ? items - item0 : G);
+    const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+    const uint32_t mask = (1u << basebit) - 1;
+    // pack the digits of every a'_i of every gate: digit j sits at bits [j*basebit, (j+1)*basebit)
+    for (int32_t idx = tid; idx < G * N; idx += nthreads) {
+        const int32_t g = idx / N, i = idx - g * N;
+        uint32_t packed = 0;
+        if (g < gcount) {
+            const uint32_t a = (uint32_t)ext[(size_t)(item0 + g) * (N + 4) + i] + prec_offset;
+            for (int32_t j = 0; j < t; j++) packed |= ((a >> (32 - (j + 1) * basebit)) & mask) << (j * basebit);
+        }
+        dw[idx] = (uint16_t)packed;
+    }
+    if (tid < G) bprime[tid] = tid < gcount ? ext[(size_t)(item0 + tid) * (N + 4) + N] : 0;
+    __syncthreads();
+
+    const int32_t nvec = stride >> 2;
+    const int32_t col = tid;  // one int4 column per thread
+    const bool active = col < nvec;
+    const int4* kbase = reinterpret_cast<const int4*>(K.ksk) + (active ? col : 0);  // idle lanes shadow column 0
+    const size_t rowpitch = (size_t)nvec;  // int4 per row; rows [pos][d] are consecutive
+    int4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) acc[g] = make_int4(0, 0, 0, 0);
+
+    // Walk i (the extracted coefficient), then its t digits.  The packed digits of a'_i of all
+    // G gates are pulled into SGPRs once per i.  Candidate rows are requested two positions
+    // ahead into a ring of three named row sets (the walk is latency-bound otherwise).
+    // Selection is branch-free: a digit picks one of the three rows (or nothing) through
+    // wave-uniform v_cndmask masks.
+    const size_t npos = (size_t)N * t;
+#define KS_LOAD(A, B, C, POS)                                        \
+    {                                                                \
+        size_t pp_ = (POS);                                          \
+        if (pp_ >= npos) pp_ = npos - 1;                             \
+        const int4* row_ = kbase + pp_ * 4 * rowpitch;               \
+        A = row_[1 * rowpitch];                                      \
+        B = row_[2 * rowpitch];                                      \
+        C = row_[3 * rowpitch];                                      \
+    }
+#define KS_USE(A, B, C, SH)                                                        \
+    _Pragma("unroll") for (int g = 0; g < G; g++) {                                \
+        const uint32_t d_ = (dg[g] >> (SH)) & mask;                                \
+        const bool is1 = d_ == 1, is2 = d_ == 2, is3 = d_ == 3;                    \
+        acc[g].x -= is1 ? A.x : (is2 ? B.x : (is3 ? C.x : 0));                     \
+        acc[g].y -= is1 ? A.y : (is2 ? B.y : (is3 ? C.y : 0));                     \
+        acc[g].z -= is1 ? A.z : (is2 ? B.z : (is3 ? C.z : 0));                     \
+        acc[g].w -= is1 ? A.w : (is2 ? B.w : (is3 ? C.w : 0));                     \
+    }
+    int4 a1, a2, a3, b1, b2, b3, c1, c2, c3;
+    KS_LOAD(a1, a2, a3, 0)
+    KS_LOAD(b1, b2, b3, 1)
+    size_t pos = 0;
+    for (int32_t i = 0; i < N; i++) {
+        uint32_t dg[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) dg[g] = __builtin_amdgcn_readfirstlane((uint32_t)dw[g * N + i]);
+        int32_t sh = 0;
+        for (int32_t j = 0; j < t; j++, pos++, sh += basebit) {
+            KS_LOAD(c1, c2, c3, pos + 2)
+            KS_USE(a1, a2, a3, sh)
+            a1 = b1; a2 = b2; a3 = b3;
+            b1 = c1; b2 = c2; b3 = c3;
+        }
+    }
+#undef KS_LOAD
+#undef KS_USE
+    if (active) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (g < gcount) {
+                int4 v = acc[g];
+                if (col == (n >> 2)) {  // the column holding b'
+                    const int32_t bp = bprime[g];
+                    switch (n & 3) {
+                        case 0: v.x += bp; break;
+                        case 1: v.y += bp; break;
+                        case 2: v.z += bp; break;
+                        default: v.w += bp; break;
+                    }
+                }
+                Torus32* out = flat_out ? flat_out + (size_t)(item0 + g) * stride : resolve(W, W.item0 + item0 + g, stride).out;
+                reinterpret_cast<int4*>(out)[col] = v;
+            }
+        }
+    }
+}
+
 // outputs of a circuit: out[b][o] = +-store[b][slot] or the constant
 __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus32* store, int32_t n_slots,
                                  Torus32* out, int64_t batch, int32_t stride, int32_t n) {
@@ -379,6 +487,9 @@ struct Evaluator::Impl {
     size_t d_outs_cap = 0;
     size_t br_lds = 0, ks_lds = 0, ksv_lds = 0;
     int ks_nld = 0;  // dwordx4 loads per KSK row per wave; 0 = use the scalar kernel
+    bool ks_batch_ok = false;     // gate-batched key switch usable (base == 4, digits fit 16 bits, columns fit 8 waves)
+    int64_t ks_batch_min = 6144;  // use it from this many gate instances per launch (one workgroup walk takes ~6 ms)
+    int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
 };
 
 Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(new Impl) {
@@ -425,6 +536,11 @@ Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(n
     {
         const int nvec = K.stride / 4, nld = (nvec + 63) / 64;
         d_->ksv_lds = (size_t)(p.N + 4) * 4 + (size_t)p.N * p.ks_t * 4 + (size_t)8 * K.stride * 4;
+        d_->ks_batch_ok = K.ks_base == 4 && p.ks_t * p.ks_basebit <= 16 && p.ks_t % 4 == 0 && nld <= 4;
+        if (const char* e = getenv("IEACHE_KS_BATCH_MIN")) d_->ks_batch_min = atoll(e);
+        if (d_->ks_batch_ok)
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_keyswitch_batch<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)((size_t)16 * p.N * 2 + 64)));
         if (nld <= 4 && d_->ksv_lds <= 160 * 1024) {
             d_->ks_nld = nld;
             const void* f = nld == 1 ? (const void*)k_keyswitch_vec<1> : nld == 2 ? (const void*)k_keyswitch_vec<2>
@@ -455,6 +571,21 @@ Evaluator::~Evaluator() {
 void Evaluator::set_chunk(size_t items) {
     if (items < 1) items = 1;
     d_->chunk = items;
+}
+
+bool Evaluator::set_option(const std::string& name, int64_t value) {
+    if (name == "chunk" && value >= 1) {
+        set_chunk((size_t)value);
+    } else if (name == "force_generic") {
+        force_generic_ = value != 0;
+    } else if (name == "ks_batch_min" && value >= 0) {
+        d_->ks_batch_min = value;
+    } else if (name == "br_slice" && value >= 1 && value <= 64) {
+        d_->br_slice = (int32_t)value;
+    } else {
+        return false;
+    }
+    return true;
 }
 
 std::string Evaluator::kernel_variant() const {
@@ -542,7 +673,7 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
             HIP_CHECK(hipMalloc(&d->br_state, items * w64::state_bytes_per_item(p)));
             d->br_state_items = items;
         }
-        return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, stream);
+        return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, d->br_slice, stream);
     }
     else
         hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,
@@ -555,6 +686,13 @@ static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkD
     const DevKeys& K = d->K;
     const dim3 grid((unsigned)cnt), blk(kKsThreads);
     const int nld = force_generic ? 0 : d->ks_nld;
+    if (nld > 0 && d->ks_batch_ok && cnt >= d->ks_batch_min) {
+        constexpr int G = 16;
+        const size_t lds = (size_t)G * K.N * 2 + (size_t)G * 4;
+        hipLaunchKernelGGL(k_keyswitch_batch<G>, dim3((unsigned)((cnt + G - 1) / G)), dim3(64 * nld), lds, stream, K, w, ext,
+                           flat_out, cnt);
+        return;
+    }
     switch (nld) {
         case 1: hipLaunchKernelGGL(k_keyswitch_vec<1>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
         case 2: hipLaunchKernelGGL(k_keyswitch_vec<2>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;

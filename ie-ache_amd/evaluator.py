@@ -108,6 +108,7 @@ def lib():
     L.ieache_ctx_cloud_run.argtypes = [vp, C.c_char_p]
     L.ieache_ctx_set_chunk.argtypes = [vp, C.c_int64]
     L.ieache_ctx_force_generic.argtypes = [vp, C.c_int]
+    L.ieache_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.ieache_ctx_kernel_variant.restype = C.c_char_p
     L.ieache_ctx_kernel_variant.argtypes = [vp]
     L.ieache_circuit_info_get.argtypes = [C.c_int, C.c_int, C.POINTER(CircuitInfo)]
@@ -225,6 +226,10 @@ class Context:
 
     def set_chunk(self, items):
         check(lib().ieache_ctx_set_chunk(self.h, items))
+
+    def set_option(self, name, value):
+        """Tuning knobs: chunk, force_generic, ks_batch_min, br_slice."""
+        check(lib().ieache_ctx_set_option(self.h, name.encode(), int(value)))
 
     def force_generic(self, on=True):
         check(lib().ieache_ctx_force_generic(self.h, int(on)))

@@ -303,3 +303,34 @@ def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
     code, bit_size, words = tools.verif(tmp_path)
     assert bit_size == 64 and tools.verif_interpret(1, code, bit_size, words) == 1000 * 2000 + 77
     assert (tmp_path / "averagestandard.txt").exists()  # MUL timing log (cloud.c:2467-2471)
+
+
+def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
+    """Fast (two-waves-per-gate, sliced) and generic kernels, every slice size, both key-switch
+    kernels: all must produce identical bits (and the oracle's)."""
+    kb, ctx = gpu_ctx(16, 1024)
+    assert "radix8" in ctx.kernel_variant
+    rng = np.random.default_rng(3)
+    bits = rng.integers(0, 2, size=(2, 2304)).astype(np.uint8)
+    a, b = kb.enc(bits[0], 41), kb.enc(bits[1], 42)
+    ref = ctx.gates(ia.GATE_AND, a, b)                     # defaults: slice 16, per-gate key switch (< 6144 gates)
+    assert np.array_equal(kb.dec(ref), bits[0] & bits[1])
+    for i in (0, 1, 2303):
+        assert np.array_equal(kb.ck.gate("and", a[i], b[i]), ref[i])
+    for sl in (1, 5, 16, 64):                              # n=16: 16, 4, 1, 1 launches; 5 leaves a ragged last slice
+        ctx.set_option("br_slice", sl)
+        assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref), sl
+    ctx.set_option("br_slice", 16)
+    ctx.set_option("ks_batch_min", 1 << 40)                # per-gate vectorised key switch
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
+    ctx.set_option("ks_batch_min", 1)                      # gate-batched key switch even for tiny launches
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a[:37], b[:37]), ref[:37])  # ragged last group of 16
+    ctx.set_option("ks_batch_min", 6144)
+    ctx.force_generic(True)
+    assert ctx.kernel_variant == "generic-radix2"
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
+    ctx.force_generic(False)
+    with pytest.raises(ia.IeacheError):
+        ctx.set_option("br_slice", 65)
+    with pytest.raises(ia.IeacheError):
+        ctx.set_option("no_such_knob", 1)
