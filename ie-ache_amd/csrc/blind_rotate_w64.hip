@@ -69,13 +69,6 @@ __device__ __forceinline__ void dft8(double2 (&x)[8]) {
     x[7] = make_double2(fma(-kR, d.x, e2.x), fma(-kR, d.y, e2.y));
 }
 
-// x[k] *= t[k] for k >= K0 (CONJ: by the conjugates)
-template <bool CONJ, int K0>
-__device__ __forceinline__ void twiddle_tab(double2 (&x)[8], const double2 (&t)[8]) {
-#pragma unroll
-    for (int k = K0; k < 8; k++) x[k] = cmulx<CONJ>(x[k], t[k]);
-}
-
 // Orders this wave's LDS traffic without a workgroup barrier: the DS instructions of
 // one wave execute in issue order, so only the compiler has to be held back.
 __device__ __forceinline__ void wave_sync() {
@@ -102,26 +95,35 @@ __device__ __forceinline__ void tile_sync() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Per-lane twiddles, built once per kernel and used by every transform in both
+// Twiddle table, one per workgroup in LDS (9 KiB), used by every transform in both
 // directions (the inverse multiplies by the conjugates):
-//   t1[k] = exp(i*pi*lane/1024) * exp(-2*pi*i*lane*k/512)   twist (lane part) x first inter-pass twiddle
-//   t2[k] = exp(-2*pi*i*(lane&7)*k/64), k = 1..7            second inter-pass twiddle
+//   tw[k*64 + lane]       = exp(i*pi*lane/1024) * exp(-2*pi*i*lane*k/512)   twist (lane part) x first inter-pass twiddle
+//   tw[512 + k*8 + p0]    = exp(-2*pi*i*p0*k/64)                            second inter-pass twiddle, p0 = lane & 7
+// Keeping them in registers costs 60 VGPRs per wave, which the BK prefetch needs more.
+constexpr int kTwElems = 8 * 64 + 8 * 8;
 struct LaneRoots {
-    double2 t1[8];
-    double2 t2[8];  // t2[0] unused
+    const double2* t1;  // &tw[lane], stride 64
+    const double2* t2;  // &tw[512 + (lane & 7)], stride 8
 };
 
-__device__ __forceinline__ LaneRoots make_roots(int lane) {
-    LaneRoots r;
+__device__ __forceinline__ void build_twiddles(double2* tw, int tid, int nthreads) {
     double s, c;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        // lane/1024 - 2*lane*k/512 = lane*(1 - 4k)/1024
-        sincospi((double)(lane * (1 - 4 * k)) / 1024.0, &s, &c);
-        r.t1[k] = make_double2(c, s);
-        sincospi(-(double)((lane & 7) * k) / 32.0, &s, &c);
-        r.t2[k] = make_double2(c, s);
+    for (int idx = tid; idx < 512; idx += nthreads) {
+        const int k = idx >> 6, lane = idx & 63;
+        sincospi((double)(lane * (1 - 4 * k)) / 1024.0, &s, &c);  // lane/1024 - 2*lane*k/512
+        tw[idx] = make_double2(c, s);
     }
+    for (int idx = tid; idx < 64; idx += nthreads) {
+        const int k = idx >> 3, p0 = idx & 7;
+        sincospi(-(double)(p0 * k) / 32.0, &s, &c);
+        tw[512 + idx] = make_double2(c, s);
+    }
+}
+
+__device__ __forceinline__ LaneRoots make_roots(const double2* tw, int lane) {
+    LaneRoots r;
+    r.t1 = tw + lane;
+    r.t2 = tw + 512 + (lane & 7);
     return r;
 }
 
@@ -138,16 +140,24 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
     const int blk = hi * 72 + lo;  // (h, l) = (lane>>3, lane&7)
+    // twiddles are fetched from the LDS table ahead of the butterflies that hide their latency
+    double2 tA[8], tB[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
     dft8<false>(x);                          // over r -> k0
-    twiddle_tab<false, 0>(x, R.t1);          // * tL * w512^(lane*k0)
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = cmulx<false>(x[k], tA[k]);  // * tL * w512^(lane*k0)
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0++) sT[own + 72 * k0] = x[k0];   // element (k0, p1, p0), lane = (p1, p0)
     tile_sync<WSYNC>();
 #pragma unroll
     for (int p1 = 0; p1 < 8; p1++) x[p1] = sT[blk + 9 * p1];    // lane = (k0, p0)
+#pragma unroll
+    for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
     tile_sync<WSYNC>();
     dft8<false>(x);                          // over p1 -> k1 ; lane = 8*k0 + p0
-    twiddle_tab<false, 1>(x, R.t2);          // * w64^(p0*k1)
+#pragma unroll
+    for (int k = 1; k < 8; k++) x[k] = cmulx<false>(x[k], tB[k]);  // * w64^(p0*k1)
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) sT[blk + 9 * k1] = x[k1];    // element (k0, k1, p0), lane = (k0, p0)
     tile_sync<WSYNC>();
@@ -167,14 +177,20 @@ template <bool WSYNC>
 __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo, blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
+    double2 tA[8], tB[8];
+#pragma unroll
+    for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
     dft8<true>(x);  // k2 -> p0 ; lane = (k0, k1)
 #pragma unroll
     for (int q = 0; q < 8; q++) sT[rd + q] = x[q];              // element (k0, k1, p0)
     tile_sync<WSYNC>();
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = sT[blk + 9 * k];         // lane = (k0, p0)
+#pragma unroll
+    for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
     tile_sync<WSYNC>();
-    twiddle_tab<true, 1>(x, R.t2);
+#pragma unroll
+    for (int k = 1; k < 8; k++) x[k] = cmulx<true>(x[k], tB[k]);
     dft8<true>(x);  // k1 -> p1 ; lane = 8*k0 + p0
 #pragma unroll
     for (int p1 = 0; p1 < 8; p1++) sT[blk + 9 * p1] = x[p1];    // element (k0, p1, p0)
@@ -182,7 +198,8 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0++) x[k0] = sT[own + 72 * k0];   // lane = (p1, p0)
     tile_sync<WSYNC>();
-    twiddle_tab<true, 0>(x, R.t1);  // conj(tL * w1^k0); the 1/512 is folded into untwist_reg()
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = cmulx<true>(x[k], tA[k]);  // conj(tL * w1^k0); 1/512 is in untwist_reg()
     dft8<true>(x);  // k0 -> r
 }
 
@@ -208,8 +225,11 @@ __device__ __forceinline__ double2 untwist_reg(int r) {
 // bkf layout: [n][2L rows][q = 2*c + limb][k2 = 8][lane = 64]
 __global__ __launch_bounds__(64) void k_bk_to_spectrum_w64(const Torus32* bk_raw, double2* bkf) {
     __shared__ __align__(16) double2 sT[kTile];
+    __shared__ __align__(16) double2 sTw[kTwElems];
     const int lane = threadIdx.x;
-    const LaneRoots R = make_roots(lane);
+    build_twiddles(sTw, lane, 64);
+    __syncthreads();
+    const LaneRoots R = make_roots(sTw, lane);
     const size_t poly = blockIdx.x;  // (i * 2L + row) * 2 + c
     const Torus32* src = bk_raw + poly * kN;
     const size_t irow = poly >> 1, c = poly & 1;
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(128) void k_br_prologue(DevKeys K, WorkDesc W, uint
 // transforms), owns the spectrum-domain sums of OUTPUT polynomial w (both
 // limbs) and inverse-transforms them.  Each forward spectrum is handed to the
 // partner wave through the producing wave's own (then idle) transpose tile.
-// dynamic LDS: sT [2][kTile] double2 | acc [2][1024] int32
+// dynamic LDS: sT [2][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32
 template <int L, int BGBIT, bool DIAG, bool WSYNC>
 __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf,
                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
@@ -280,14 +300,16 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
                                                            unsigned long long* diag) {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* sT_all = reinterpret_cast<double2*>(smem);
-    int32_t* acc = reinterpret_cast<int32_t*>(sT_all + 2 * kTile);
+    double2* sTw = sT_all + 2 * kTile;
+    int32_t* acc = reinterpret_cast<int32_t*>(sTw + kTwElems);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double2* sT = sT_all + wave * kTile;
     const double2* sTp = sT_all + (wave ^ 1) * kTile;
     const int64_t item = (int64_t)blockIdx.x;
     const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
     int32_t* gacc = st_acc + (size_t)item * 2 * kN;
-    const LaneRoots R = make_roots(lane);
+    build_twiddles(sTw, tid, 128);
+    const LaneRoots R = make_roots(sTw, lane);
     {
         const int4* src = reinterpret_cast<const int4*>(gacc);
         int4* dst = reinterpret_cast<int4*>(acc);
@@ -346,28 +368,37 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
                 const int32_t e1 = (int32_t)((v1[r] >> sh) & maskBg) - (int32_t)halfBg;
                 x[r] = cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
-            double2 bpre[8];
+            // BK loads are issued well ahead of their use (each is an L2 round trip of ~700 cycles):
+            //   bA = own row, limb 0      before the transform
+            //   bB = own row, limb 1      } right after it, consumed behind bA's MACs
+            //   bC = partner row, limb 0  }
+            //   bD = partner row, limb 1  after bA is consumed (reuses its registers)
+            double2 bA[8], bB[8], bC[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) bA[k] = bown[k * 64];
+            __builtin_amdgcn_sched_barrier(0);
             fft512_forward<WSYNC>(x, sT, lane, R);
             IEACHE_STAMP(1)
             // hand the spectrum to the partner wave through our own (now idle) tile
 #pragma unroll
             for (int k = 0; k < 8; k++) sT[k * 64 + lane] = x[k];
-            // own row: s[o] += x * B[own row][2*wave + o]
 #pragma unroll
-            for (int k = 0; k < 8; k++) bpre[k] = bown[k * 64];
-            {
-                double2 b[8];
+            for (int k = 0; k < 8; k++) bB[k] = bown[(8 + k) * 64];
 #pragma unroll
-                for (int k = 0; k < 8; k++) b[k] = bown[(8 + k) * 64];
+            for (int k = 0; k < 8; k++) bC[k] = bpar[k * 64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 8; k++)
-                    s[0][k] = make_double2(fma(x[k].x, bpre[k].x, fma(-x[k].y, bpre[k].y, s[0][k].x)),
-                                           fma(x[k].x, bpre[k].y, fma(x[k].y, bpre[k].x, s[0][k].y)));
+            for (int k = 0; k < 8; k++)
+                s[0][k] = make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[0][k].x)),
+                                       fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[0][k].y)));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 8; k++)
-                    s[1][k] = make_double2(fma(x[k].x, b[k].x, fma(-x[k].y, b[k].y, s[1][k].x)),
-                                           fma(x[k].x, b[k].y, fma(x[k].y, b[k].x, s[1][k].y)));
-            }
+            for (int k = 0; k < 8; k++) bA[k] = bpar[(8 + k) * 64];  // bD
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[1][k] = make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
+                                       fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
             IEACHE_STAMP(2)
             __syncthreads();
             IEACHE_STAMP(3)
@@ -375,15 +406,13 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 #pragma unroll
             for (int k = 0; k < 8; k++) x[k] = sTp[k * 64 + lane];
 #pragma unroll
-            for (int o = 0; o < 2; o++) {
-                double2 b[8];
+            for (int k = 0; k < 8; k++)
+                s[0][k] = make_double2(fma(x[k].x, bC[k].x, fma(-x[k].y, bC[k].y, s[0][k].x)),
+                                       fma(x[k].x, bC[k].y, fma(x[k].y, bC[k].x, s[0][k].y)));
 #pragma unroll
-                for (int k = 0; k < 8; k++) b[k] = bpar[(o * 8 + k) * 64];
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    s[o][k] = make_double2(fma(x[k].x, b[k].x, fma(-x[k].y, b[k].y, s[o][k].x)),
-                                           fma(x[k].x, b[k].y, fma(x[k].y, b[k].x, s[o][k].y)));
-            }
+            for (int k = 0; k < 8; k++)
+                s[1][k] = make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[1][k].x)),
+                                       fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[1][k].y)));
             IEACHE_STAMP(4)
             __syncthreads();  // partner has read our tile before the next transform reuses it
             IEACHE_STAMP(5)
@@ -438,7 +467,7 @@ size_t spectrum_elems(const Params& p) { return (size_t)p.n * p.kpl() * 4 * kM; 
 
 size_t lds_bytes(const Params& p) {
     (void)p;
-    return (size_t)2 * kTile * sizeof(double2) + (size_t)2 * kN * 4;
+    return (size_t)(2 * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
 }
 
 int32_t bara_stride(const Params& p) { return (p.n + 7) & ~7; }
@@ -500,14 +529,14 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
         launches++;
         switch (variant) {
             case 1: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
-            case 2: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
-            default: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
+            case 2: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
+            default: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
         }
     }
     if (variant == 1) diag_report(stream, items, nsteps);
     if (nsteps == 0 && ext) {
         // degenerate (steps == 0): extraction straight from the initial accumulator
-        hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext,
+        hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext,
                            (unsigned long long*)nullptr);
     }
     if (dbg_acc)
