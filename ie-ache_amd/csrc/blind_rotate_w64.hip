@@ -127,6 +127,77 @@ __device__ __forceinline__ LaneRoots make_roots(const double2* tw, int lane) {
     return r;
 }
 
+// ---- register <-> lane transposes without LDS ----
+// Both transposes of the 8x8x8 transform swap the 3 bits of the register index with 3 bits
+// of the lane index.  Swapping ONE register bit with ONE lane bit B is an exchange between
+// lanes l and l ^ (1 << B): v_permlane32_swap / v_permlane16_swap do exactly that for B = 5, 4
+// (one instruction per dword pair), DPP row/quad moves for B = 3..0.
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+template <int B>
+__device__ __forceinline__ void swap_dwords(unsigned& lo, unsigned& hi, int lane) {
+    // lo: a dword of x[r] (register bit clear), hi: the same dword of x[r | bit].
+    // After the call, lanes with bit B clear hold in `hi` what the partner lane had in `lo`, and
+    // lanes with bit B set hold in `lo` what the partner had in `hi`.
+    if constexpr (B == 5) {
+        const v2u_t r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0];
+        hi = r[1];
+    } else if constexpr (B == 4) {
+        const v2u_t r = __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
+        lo = r[0];
+        hi = r[1];
+    } else if constexpr (B == 3) {
+        const unsigned nh = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)lo, 0x128, 0xF, 0x3, false);  // row_ror:8
+        const unsigned nl = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)hi, 0x128, 0xF, 0xC, false);
+        lo = nl;
+        hi = nh;
+    } else if constexpr (B == 2) {
+        const unsigned nh = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)lo, 0x104, 0xF, 0x5, false);  // row_shl:4
+        const unsigned nl = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)hi, 0x114, 0xF, 0xA, false);  // row_shr:4
+        lo = nl;
+        hi = nh;
+    } else {
+        constexpr int ctrl = B == 1 ? 0x4E : 0xB1;  // quad_perm [2,3,0,1] / [1,0,3,2]
+        const unsigned tl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, ctrl, 0xF, 0xF, true);
+        const unsigned th = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, ctrl, 0xF, 0xF, true);
+        const bool set = (lane >> B) & 1;
+        hi = set ? hi : tl;
+        lo = set ? th : lo;
+    }
+}
+
+template <int B>
+__device__ __forceinline__ void bitswap(double2 (&x)[8], int lane) {
+    constexpr int m = 1 << (B % 3);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (r & m) continue;
+        unsigned a0 = (unsigned)__double2loint(x[r].x), a1 = (unsigned)__double2hiint(x[r].x);
+        unsigned a2 = (unsigned)__double2loint(x[r].y), a3 = (unsigned)__double2hiint(x[r].y);
+        unsigned b0 = (unsigned)__double2loint(x[r | m].x), b1 = (unsigned)__double2hiint(x[r | m].x);
+        unsigned b2 = (unsigned)__double2loint(x[r | m].y), b3 = (unsigned)__double2hiint(x[r | m].y);
+        swap_dwords<B>(a0, b0, lane);
+        swap_dwords<B>(a1, b1, lane);
+        swap_dwords<B>(a2, b2, lane);
+        swap_dwords<B>(a3, b3, lane);
+        x[r] = make_double2(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)a3, (int)a2));
+        x[r | m] = make_double2(__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2));
+    }
+}
+// register index <-> lane bits 3..5 (what the first LDS transpose does)
+__device__ __forceinline__ void xlane_hi(double2 (&x)[8], int lane) {
+    bitswap<3>(x, lane);
+    bitswap<4>(x, lane);
+    bitswap<5>(x, lane);
+}
+// register index <-> lane bits 0..2 (what the second LDS transpose does)
+__device__ __forceinline__ void xlane_lo(double2 (&x)[8], int lane) {
+    bitswap<0>(x, lane);
+    bitswap<1>(x, lane);
+    bitswap<2>(x, lane);
+}
+
 // Transpose tiles hold element (h, m, l) -- three 3-bit digits -- at h*72 + m*9 + l.
 // The 9/72 padding makes every ds_write_b128 / ds_read_b128 of both transposes
 // bank-conflict free AND lets each access be "per-lane base + immediate offset".
@@ -135,7 +206,7 @@ constexpr int kTile = 8 * 72;  // double2 elements per tile (9216 B)
 // Forward 512-point transform of the twisted polynomial.
 //   in : x[r] = y_{64r+lane} * exp(i*pi*r/16)  (the lane part tL of the twist is applied here)
 //   out: x[k2] = X[k0 + 8*k1 + 64*k2] with lane = 8*k0 + k1
-template <bool WSYNC>
+template <bool WSYNC, bool XLANE = false>
 __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
@@ -148,32 +219,38 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = cmulx<false>(x[k], tA[k]);  // * tL * w512^(lane*k0)
 #pragma unroll
-    for (int k0 = 0; k0 < 8; k0++) sT[own + 72 * k0] = x[k0];   // element (k0, p1, p0), lane = (p1, p0)
-    tile_sync<WSYNC>();
-#pragma unroll
-    for (int p1 = 0; p1 < 8; p1++) x[p1] = sT[blk + 9 * p1];    // lane = (k0, p0)
-#pragma unroll
     for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
-    tile_sync<WSYNC>();
+    if (XLANE) {
+        xlane_hi(x, lane);                                          // reg k0 <-> lane bits 3..5: lane = (k0, p0), reg = p1
+    } else {
+#pragma unroll
+        for (int k0 = 0; k0 < 8; k0++) sT[own + 72 * k0] = x[k0];   // element (k0, p1, p0), lane = (p1, p0)
+        tile_sync<WSYNC>();
+#pragma unroll
+        for (int p1 = 0; p1 < 8; p1++) x[p1] = sT[blk + 9 * p1];    // lane = (k0, p0)
+        tile_sync<WSYNC>();
+    }
     dft8<false>(x);                          // over p1 -> k1 ; lane = 8*k0 + p0
 #pragma unroll
     for (int k = 1; k < 8; k++) x[k] = cmulx<false>(x[k], tB[k]);  // * w64^(p0*k1)
+    if (XLANE) {
+        xlane_lo(x, lane);                                          // reg k1 <-> lane bits 0..2: lane = (k0, k1), reg = p0
+    } else {
 #pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) sT[blk + 9 * k1] = x[k1];    // element (k0, k1, p0), lane = (k0, p0)
-    tile_sync<WSYNC>();
-    {
-        const int rd = hi * 72 + lo * 9;                         // lane = (k0, k1)
+        for (int k1 = 0; k1 < 8; k1++) sT[blk + 9 * k1] = x[k1];    // element (k0, k1, p0), lane = (k0, p0)
+        tile_sync<WSYNC>();
+        const int rd = hi * 72 + lo * 9;                            // lane = (k0, k1)
 #pragma unroll
         for (int q = 0; q < 8; q++) x[q] = sT[rd + q];
+        tile_sync<WSYNC>();
     }
-    tile_sync<WSYNC>();
     dft8<false>(x);                          // over p0 -> k2 ; lane = 8*k0 + k1
 }
 
 // Inverse of fft512_forward (unnormalised: 512 x), also removing the lane part of the twist:
 //   in : spectrum in the layout fft512_forward produces
 //   out: x[r] = y_{64r+lane} * exp(i*pi*r/16)   (caller multiplies by exp(-i*pi*r/16))
-template <bool WSYNC>
+template <bool WSYNC, bool XLANE = false>
 __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo, blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
@@ -182,22 +259,30 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int
     for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
     dft8<true>(x);  // k2 -> p0 ; lane = (k0, k1)
 #pragma unroll
-    for (int q = 0; q < 8; q++) sT[rd + q] = x[q];              // element (k0, k1, p0)
-    tile_sync<WSYNC>();
-#pragma unroll
-    for (int k = 0; k < 8; k++) x[k] = sT[blk + 9 * k];         // lane = (k0, p0)
-#pragma unroll
     for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
-    tile_sync<WSYNC>();
+    if (XLANE) {
+        xlane_lo(x, lane);                                          // back to lane = (k0, p0), reg = k1
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) sT[rd + q] = x[q];              // element (k0, k1, p0)
+        tile_sync<WSYNC>();
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = sT[blk + 9 * k];         // lane = (k0, p0)
+        tile_sync<WSYNC>();
+    }
 #pragma unroll
     for (int k = 1; k < 8; k++) x[k] = cmulx<true>(x[k], tB[k]);
     dft8<true>(x);  // k1 -> p1 ; lane = 8*k0 + p0
+    if (XLANE) {
+        xlane_hi(x, lane);                                          // back to lane = (p1, p0), reg = k0
+    } else {
 #pragma unroll
-    for (int p1 = 0; p1 < 8; p1++) sT[blk + 9 * p1] = x[p1];    // element (k0, p1, p0)
-    tile_sync<WSYNC>();
+        for (int p1 = 0; p1 < 8; p1++) sT[blk + 9 * p1] = x[p1];    // element (k0, p1, p0)
+        tile_sync<WSYNC>();
 #pragma unroll
-    for (int k0 = 0; k0 < 8; k0++) x[k0] = sT[own + 72 * k0];   // lane = (p1, p0)
-    tile_sync<WSYNC>();
+        for (int k0 = 0; k0 < 8; k0++) x[k0] = sT[own + 72 * k0];   // lane = (p1, p0)
+        tile_sync<WSYNC>();
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = cmulx<true>(x[k], tA[k]);  // conj(tL * w1^k0); 1/512 is in untwist_reg()
     dft8<true>(x);  // k0 -> r
@@ -293,7 +378,7 @@ __global__ __launch_bounds__(128) void k_br_prologue(DevKeys K, WorkDesc W, uint
 // limbs) and inverse-transforms them.  Each forward spectrum is handed to the
 // partner wave through the producing wave's own (then idle) transpose tile.
 // dynamic LDS: sT [2][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32
-template <int L, int BGBIT, bool DIAG, bool WSYNC>
+template <int L, int BGBIT, bool DIAG, bool WSYNC, bool XLANE = false>
 __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf,
                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
                                                            int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
@@ -377,7 +462,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 #pragma unroll
             for (int k = 0; k < 8; k++) bA[k] = bown[k * 64];
             __builtin_amdgcn_sched_barrier(0);
-            fft512_forward<WSYNC>(x, sT, lane, R);
+            fft512_forward<WSYNC, XLANE>(x, sT, lane, R);
             IEACHE_STAMP(1)
             // hand the spectrum to the partner wave through our own (now idle) tile
 #pragma unroll
@@ -421,7 +506,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
         uint32_t lo0[8], lo1[8];
 #pragma unroll
         for (int limb = 0; limb < 2; limb++) {
-            fft512_inverse<WSYNC>(s[limb], sT, lane, R);
+            fft512_inverse<WSYNC, XLANE>(s[limb], sT, lane, R);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const double2 z = cmulx<true>(s[limb][r], untwist_reg(r));
@@ -505,15 +590,19 @@ static void diag_report(hipStream_t stream, int64_t items, int32_t nsteps) {
     }
 }
 
+int32_t default_variant() {
+    static const int32_t v = getenv("IEACHE_BR_VARIANT") ? atoi(getenv("IEACHE_BR_VARIANT")) : 0;
+    return v;
+}
+
 int32_t default_slice() {
     static const int32_t s = getenv("IEACHE_BR_SLICE") ? atoi(getenv("IEACHE_BR_SLICE")) : 16;
     return s > 0 ? (s < 64 ? s : 64) : 16;  // <= 64: one rotation amount per lane
 }
 
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDesc& W, int64_t items, void* state,
-           Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, hipStream_t stream) {
+           Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant, hipStream_t stream) {
     int launches = 0;
-    static const int variant = getenv("IEACHE_BR_VARIANT") ? atoi(getenv("IEACHE_BR_VARIANT")) : 0;
     const dim3 grid((unsigned)items), blk(128);
     const size_t lds = lds_bytes(p);
     const int32_t nb = bara_stride(p);
@@ -530,10 +619,12 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
         switch (variant) {
             case 1: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
             case 2: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
+            case 3: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
+            case 4: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, true, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
             default: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
         }
     }
-    if (variant == 1) diag_report(stream, items, nsteps);
+    if (variant == 1 || variant == 4) diag_report(stream, items, nsteps);
     if (nsteps == 0 && ext) {
         // degenerate (steps == 0): extraction straight from the initial accumulator
         hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext,

@@ -490,6 +490,7 @@ struct Evaluator::Impl {
     bool ks_batch_ok = false;     // gate-batched key switch usable (base == 4, digits fit 16 bits, columns fit 8 waves)
     int64_t ks_batch_min = 6144;  // use it from this many gate instances per launch (one workgroup walk takes ~6 ms)
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
+    int32_t br_variant = w64::default_variant();
 };
 
 Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(new Impl) {
@@ -582,6 +583,8 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->ks_batch_min = value;
     } else if (name == "br_slice" && value >= 1 && value <= 64) {
         d_->br_slice = (int32_t)value;
+    } else if (name == "br_variant" && value >= 0 && value <= 4) {
+        d_->br_variant = (int32_t)value;
     } else {
         return false;
     }
@@ -673,7 +676,7 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
             HIP_CHECK(hipMalloc(&d->br_state, items * w64::state_bytes_per_item(p)));
             d->br_state_items = items;
         }
-        return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, d->br_slice, stream);
+        return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, d->br_slice, d->br_variant, stream);
     }
     else
         hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,

@@ -321,6 +321,10 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         ctx.set_option("br_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref), sl
     ctx.set_option("br_slice", 16)
+    for variant in (2, 3):                                 # workgroup-barrier sync; cross-lane (DPP/permlane) transposes
+        ctx.set_option("br_variant", variant)
+        assert np.array_equal(ctx.gates(ia.GATE_AND, a[:300], b[:300]), ref[:300]), variant
+    ctx.set_option("br_variant", 0)
     ctx.set_option("ks_batch_min", 1 << 40)                # per-gate vectorised key switch
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
     ctx.set_option("ks_batch_min", 1)                      # gate-batched key switch even for tiny launches
@@ -334,3 +338,24 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         ctx.set_option("br_slice", 65)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("no_such_knob", 1)
+
+
+def test_edge_cases_empty_batch_and_chunking(ia, gpu_ctx):
+    kb, ctx = gpu_ctx(4, 1024)
+    info = ia.circuit_info(ia.CIRC_ADD, 32)
+    empty = ctx.eval_batch(ia.CIRC_ADD, 32, np.zeros((0, info.n_inputs, kb.p.n + 1), np.int32))
+    assert empty.shape == (0, 32, kb.p.n + 1)
+    assert ctx.gates(ia.GATE_AND, np.zeros((0, kb.p.n + 1), np.int32), np.zeros((0, kb.p.n + 1), np.int32)).shape[0] == 0
+    vals = [(0xFFFFFFFF, 0xFFFFFFFF), (0, 0), (1, 0xFFFFFFFF), (0x80000000, 0x80000000), (12345, 67890)]
+    inp = _inputs(kb, 2, 32, vals, 17)
+    ref = ctx.eval_batch(ia.CIRC_SUB, 32, inp)
+    ctx.set_chunk(7)  # every level split into ragged chunks
+    st = ia.Stats()
+    assert np.array_equal(ctx.eval_batch(ia.CIRC_SUB, 32, inp, st), ref)
+    assert st.chunks > st.levels
+    ctx.set_chunk(16384)
+    ctx.force_generic(True)  # generic kernels on a whole circuit
+    assert np.array_equal(ctx.eval_batch(ia.CIRC_SUB, 32, inp), ref)
+    ctx.force_generic(False)
+    with pytest.raises(ia.IeacheError):
+        ctx.eval_batch_device(9, 32, 1, 1, 1)  # unknown circuit kind

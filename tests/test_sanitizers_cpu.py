@@ -1,0 +1,31 @@
+"""Host code under AddressSanitizer + UBSan (GPU sanitizers are not available on the pool)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_code_clean_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "asan_selftest"
+    csrc = os.path.join(ROOT, "ie-ache_amd", "csrc")
+    cxx = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-c"]
+    objs = []
+    for src in ("tfhe_host.cpp", "codec.cpp", "circuit.cpp"):
+        o = tmp_path / (src + ".o")
+        subprocess.check_call(cxx + [os.path.join(csrc, src), "-o", str(o)])
+        objs.append(str(o))
+    o = tmp_path / "selftest.o"
+    subprocess.check_call(cxx + [os.path.join(ROOT, "tests", "native", "asan_selftest.cpp"), "-o", str(o)])
+    objs.append(str(o))
+    for src in ("tfhe_oracle.c", "cloud_oracle.c"):
+        o = tmp_path / (src + ".o")
+        subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined",
+                               "-fno-sanitize-recover=undefined", "-c", os.path.join(ROOT, "oracle", src), "-o", str(o)])
+        objs.append(str(o))
+    subprocess.check_call(["g++", "-fsanitize=address,undefined"] + objs + ["-o", str(exe), "-lm"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([str(exe), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "ASAN_SELFTEST_OK" in r.stdout, r.stdout[-4000:]

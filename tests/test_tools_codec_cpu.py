@@ -164,3 +164,41 @@ def test_verif_interpretation_rules(ia):
     assert vi(2, 1, 32, w(12)) == -12                      # (-A)-B (verif.c:780-783)
     assert vi(4, 0, 64, w(1 << 60)) == 1 << 60             # 2^30 * 2^30
     assert vi(4, 1, 64, w(6)) == -6 and vi(4, 4, 64, w(6)) == 6
+
+
+def test_c_abi_error_behaviour_without_gpu(ia, tmp_path):
+    """Negative errno-style returns + a message, never an exception or a crash (SURVEY 8b conventions)."""
+    import ctypes as C
+    L = ia.lib()
+    # the process contract on a directory with no files: the reference segfaults, we report IEACHE_EIO
+    assert L.ieache_cloud_run(os.fsencode(tmp_path)) == -5
+    assert b"cloud.key" in L.ieache_last_error() or b"cannot open" in L.ieache_last_error()
+    # a context needs a key file ...
+    assert not L.ieache_ctx_create(os.fsencode(tmp_path / "nope.key"), 0)
+    assert L.ieache_last_error()
+    # ... and every entry point tolerates a null context
+    assert L.ieache_eval_batch(None, 1, 32, 1, None, None, None) == -22
+    assert L.ieache_gates_device(None, 0, 1, None, None, None, None) == -22
+    assert L.ieache_ctx_cloud_run(None, b".") == -22
+    assert L.ieache_lwe_stride(None) == -22
+    L.ieache_ctx_destroy(None)
+    # unsupported parameter sets are refused up front
+    p = ia.default_params().copy(N=1000)
+    assert L.ieache_keygen_raw(C.byref(p), None, 0, None, None, None, None) == -22
+    p = ia.default_params().copy(k=2)
+    assert L.ieache_keygen_raw(C.byref(p), None, 0, None, None, None, None) == -22
+    if ia.device_count() == 0:  # CPU box: there is no fallback path, creating a context must fail loudly
+        from ieache_amd import tools
+        q = ia.default_params().copy(n=4, N=32)
+        k = tools.keygen_raw(q, (1,))
+        with pytest.raises(ia.IeacheError):
+            ia.Context.from_arrays(q, k["bk"], k["ksk"])
+
+
+def test_missing_extension_fails_loudly(ia, monkeypatch, tmp_path):
+    """The product path must not degrade to anything else when libieache.so is absent."""
+    from ieache_amd import evaluator
+    monkeypatch.setattr(evaluator, "_LIB", None)
+    monkeypatch.setattr(evaluator, "_PKG", str(tmp_path))
+    with pytest.raises(ia.IeacheError, match="no CPU fallback"):
+        evaluator.lib()
