@@ -228,6 +228,8 @@ int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out) {
         out->bootstraps = c.n_bootstraps;
         out->n_and = c.n_and;
         out->n_xor = c.n_xor;
+        out->sched_max_width = c.sched_max_width;
+        out->reserved = 0;
         return 0;
     });
 }

@@ -101,12 +101,14 @@ struct Circuit {
     std::vector<OutRef> outputs;        // output samples per expression
     // statistics
     int64_t n_bootstraps = 0, n_and = 0, n_xor = 0;
-    int32_t depth = 0, max_width = 0;
+    int32_t depth = 0, max_width = 0;  // ASAP depth / widest ASAP level
+    int32_t sched_max_width = 0;       // widest level of the schedule actually executed
     int32_t n_levels() const { return (int32_t)level_offset.size() - 1; }
 };
 
 // Levelise + allocate slots.  `outputs` are the samples to return per expression.
-Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const Word& outputs);
+// balanced: slack-aware list schedule (default) instead of plain ASAP levels.
+Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const Word& outputs, bool balanced = true);
 
 // ---- the circuits main() dispatches to (cloud.c:870-2718) ----
 // Input sample order for all of them: operand 1 words (32 samples each, LSB
@@ -123,7 +125,9 @@ enum CircuitKind : int32_t {
 // bits: operand width.  ADD/SUB/RSUB accept any bits >= 1 (the reference uses
 // 32/64/128/256; 16 is BASELINE.json's generalisation add(...,16,...));
 // MUL accepts 32/64/128.  Returns false for unsupported combinations.
-bool build_circuit(int32_t kind, int32_t bits, Circuit* out);
+// balanced=true lets the builder pick the slack-balanced schedule where it saves memory
+// (64/128-bit multipliers); false forces plain ASAP levels.
+bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced = true);
 // number of input / output samples per expression of a circuit kind
 int32_t circuit_n_inputs(int32_t kind, int32_t bits);
 int32_t circuit_n_outputs(int32_t kind, int32_t bits);

@@ -57,7 +57,8 @@ class Stats(C.Structure):
 
 class CircuitInfo(C.Structure):
     _fields_ = [("n_inputs", C.c_int32), ("n_outputs", C.c_int32), ("n_slots", C.c_int32), ("depth", C.c_int32),
-                ("max_width", C.c_int32), ("bootstraps", C.c_int64), ("n_and", C.c_int64), ("n_xor", C.c_int64)]
+                ("max_width", C.c_int32), ("bootstraps", C.c_int64), ("n_and", C.c_int64), ("n_xor", C.c_int64),
+                ("sched_max_width", C.c_int32), ("reserved", C.c_int32)]
 
 
 def library_path():

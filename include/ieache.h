@@ -70,8 +70,10 @@ typedef struct ieache_circuit_info {
     int32_t n_outputs;   /* samples per expression, LSB first */
     int32_t n_slots;     /* wire-store rows per expression on the device */
     int32_t depth;       /* ASAP levels */
-    int32_t max_width;
+    int32_t max_width;   /* widest ASAP level */
     int64_t bootstraps, n_and, n_xor;
+    int32_t sched_max_width; /* widest level of the slack-balanced schedule the executor runs */
+    int32_t reserved;
 } ieache_circuit_info;
 
 const char* ieache_version(void);

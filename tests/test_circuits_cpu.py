@@ -83,3 +83,17 @@ def test_unsupported_circuits_rejected(ia):
     for kind, bits in [(4, 256), (4, 16), (5, 32), (9, 32), (1, 0), (1, 257)]:
         with pytest.raises(ia.IeacheError):
             ia.circuit_info(kind, bits)
+
+
+def test_slack_balanced_schedule(ia):
+    """The executor's schedule keeps the ASAP depth but spreads gates with slack over the levels."""
+    for (kind, bits), (maxw, slots) in {(4, 64): (160, 2000), (4, 128): (160, 4000), (5, 64): (160, 2000)}.items():
+        i = ia.circuit_info(kind, bits)
+        assert i.depth == APP_C[(kind, bits)][3]                 # same number of levels as ASAP
+        assert i.sched_max_width <= maxw < i.max_width           # but no 1000+-gate level 1 any more
+        assert i.sched_max_width >= -(-i.bootstraps // i.depth)  # at least the mean width
+        assert i.n_slots <= slots
+    i = ia.circuit_info(1, 32)
+    assert i.sched_max_width == 2  # a ripple adder has no slack: schedule == ASAP
+    i = ia.circuit_info(4, 32)
+    assert i.sched_max_width == i.max_width == 1056  # mul32 keeps ASAP levels (measured faster, store is small)
