@@ -272,6 +272,9 @@ int32_t circuit_n_inputs(int32_t kind, int32_t bits) {
         case CIRC_SUB:
         case CIRC_RSUB:
         case CIRC_MUL:
+        case CIRC_ADD_KS:
+        case CIRC_SUB_KS:
+        case CIRC_RSUB_KS:
             return 2 * bits + 32;
         case CIRC_MULADD:
             return 2 * bits + 32 + 2 * bits;
@@ -284,6 +287,9 @@ int32_t circuit_n_outputs(int32_t kind, int32_t bits) {
         case CIRC_ADD:
         case CIRC_SUB:
         case CIRC_RSUB:
+        case CIRC_ADD_KS:
+        case CIRC_SUB_KS:
+        case CIRC_RSUB_KS:
             return bits;
         case CIRC_MUL:
         case CIRC_MULADD:
@@ -338,6 +344,33 @@ static std::vector<Word> twos_complement(CircuitBuilder& b, const std::vector<Wo
     return twos;
 }
 
+// Kogge-Stone addition x + y + cin with XOR/AND only.  (g, p) o (g', p') = (g | p&g', p&p');
+// g and p&g' are never both 1 (g = 1 forces p = 0), so the OR is an XOR.
+static Word kogge_stone_add(CircuitBuilder& b, const Word& x, const Word& y, Ref cin) {
+    const int n = (int)x.size();
+    std::vector<Ref> g(n), p(n), p0(n);
+    for (int i = 0; i < n; i++) {
+        g[i] = b.AND(x[i], y[i]);
+        p[i] = b.XOR(x[i], y[i]);
+        p0[i] = p[i];
+    }
+    // fold the carry-in into bit 0's generate: carry out of bit 0 = g0 ^ (p0 & cin)
+    g[0] = b.XOR(g[0], b.AND(p[0], cin));
+    for (int d = 1; d < n; d <<= 1) {
+        std::vector<Ref> ng = g, np = p;
+        for (int i = d; i < n; i++) {
+            ng[i] = b.XOR(g[i], b.AND(p[i], g[i - d]));
+            if (i >= 2 * d) np[i] = b.AND(p[i], p[i - d]);  // prefixes reaching bit 0 need no more propagate
+        }
+        g.swap(ng);
+        p.swap(np);
+    }
+    Word sum(n);
+    sum[0] = b.XOR(p0[0], cin);
+    for (int i = 1; i < n; i++) sum[i] = b.XOR(p0[i], g[i - 1]);  // g[i-1] = carry into bit i
+    return sum;
+}
+
 bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced) {
     if (bits < 1 || bits > 256) return false;
     const int32_t n_in = circuit_n_inputs(kind, bits);
@@ -361,6 +394,24 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced) {
             result = chained_add(b, Bw, twos_complement(b, Aw), carry1);
             name = "rsub";
             break;
+        case CIRC_ADD_KS:
+            result = kogge_stone_add(b, A, B, carry1[0]);
+            name = "add_ks";
+            break;
+        case CIRC_SUB_KS: {  // A + ~B + 1 (the reference's carry word encrypts 0: alice.c:147-149)
+            Word nb(bits);
+            CircuitBuilder::NOT(nb, B, bits);
+            result = kogge_stone_add(b, A, nb, CircuitBuilder::constant(1));
+            name = "sub_ks";
+            break;
+        }
+        case CIRC_RSUB_KS: {
+            Word na(bits);
+            CircuitBuilder::NOT(na, A, bits);
+            result = kogge_stone_add(b, B, na, CircuitBuilder::constant(1));
+            name = "rsub_ks";
+            break;
+        }
         case CIRC_MUL:
         case CIRC_MULADD: {
             if (kind == CIRC_MULADD && bits != 64) return false;

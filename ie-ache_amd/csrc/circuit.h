@@ -120,6 +120,13 @@ enum CircuitKind : int32_t {
     CIRC_RSUB = 3,    // B + (~A+1)           cloud.c:1809-2365
     CIRC_MUL = 4,     // A*B, double width    cloud.c:2366-2718
     CIRC_MULADD = 5,  // (A*B)+C fused two-stage (compute_final chaining), 64-bit A,B
+    // parallel-prefix (Kogge-Stone) adders, still XOR/AND only.  Same inputs and
+    // outputs as ADD/SUB/RSUB and the same decrypted result (the carry word must encrypt 0, as
+    // alice.c:147-149 guarantees), but NOT the same ciphertext bits: depth 2*log2(bits)+2 instead
+    // of 3*bits, ~3.4x the bootstraps.  For small batches, where depth is what costs.
+    CIRC_ADD_KS = 6,
+    CIRC_SUB_KS = 7,
+    CIRC_RSUB_KS = 8,
 };
 
 // bits: operand width.  ADD/SUB/RSUB accept any bits >= 1 (the reference uses

@@ -14,6 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 CIRC_ADD, CIRC_SUB, CIRC_RSUB, CIRC_MUL, CIRC_MULADD = 1, 2, 3, 4, 5
+CIRC_ADD_KS, CIRC_SUB_KS, CIRC_RSUB_KS = 6, 7, 8  # Kogge-Stone variants (decrypt-identical, not bit-identical)
 GATE_AND, GATE_XOR, GATE_OR, GATE_NAND = 0, 1, 2, 3
 
 

@@ -56,6 +56,9 @@ typedef struct ieache_stats {
 #define IEACHE_CIRC_SUB 2     /* A+(~B+1)           cloud.c:1196-1807 */
 #define IEACHE_CIRC_RSUB 3    /* B+(~A+1)           cloud.c:1809-2365 */
 #define IEACHE_CIRC_MUL 4     /* A*B, double width  cloud.c:2366-2718 */
+#define IEACHE_CIRC_ADD_KS 6   /* Kogge-Stone variants of ADD/SUB/RSUB: same decrypted */
+#define IEACHE_CIRC_SUB_KS 7   /* result, depth 2*log2(bits)+2 instead of 3*bits, not the same       */
+#define IEACHE_CIRC_RSUB_KS 8  /* ciphertext bits as the reference's ripple adders                   */
 #define IEACHE_CIRC_MULADD 5  /* (A*B)+C, the compute_final() chaining of
                                  Cloud/dragonfly_cipher_cloud.py:1300-1327 fused (64-bit A,B) */
 

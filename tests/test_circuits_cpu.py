@@ -97,3 +97,21 @@ def test_slack_balanced_schedule(ia):
     assert i.sched_max_width == 2  # a ripple adder has no slack: schedule == ASAP
     i = ia.circuit_info(4, 32)
     assert i.sched_max_width == i.max_width == 1056  # mul32 keeps ASAP levels (measured faster, store is small)
+
+
+@pytest.mark.parametrize("bits", [1, 5, 16, 32, 64, 256])
+def test_kogge_stone_adders_plaintext(ia, bits):
+    """XOR/AND-only parallel-prefix adders decrypt like the ripple ones."""
+    rng = np.random.default_rng(900 + bits)
+    m = 1 << bits
+    nbytes = (bits + 7) // 8
+    cases = [(0, 0), (m - 1, 1), (m - 1, m - 1), (1, m - 1)]
+    cases += [(int.from_bytes(rng.bytes(nbytes), "little") % m, int.from_bytes(rng.bytes(nbytes), "little") % m) for _ in range(8)]
+    for a, b in cases:
+        assert _run(ia, ia.CIRC_ADD_KS, bits, a, b) == (a + b) % m
+        assert _run(ia, ia.CIRC_SUB_KS, bits, a, b) == (a - b) % m
+        assert _run(ia, ia.CIRC_RSUB_KS, bits, a, b) == (b - a) % m
+    assert _run(ia, ia.CIRC_ADD_KS, bits, 0, 0, carry_bits=1) == 1 % m  # carry-in honoured like cloud.c:24
+    if bits >= 16:
+        ks, rc = ia.circuit_info(ia.CIRC_ADD_KS, bits), ia.circuit_info(ia.CIRC_ADD, bits)
+        assert ks.depth < rc.depth // 3 and ks.n_and + ks.n_xor == ks.bootstraps  # only the reference's gate types

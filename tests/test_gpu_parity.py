@@ -359,3 +359,19 @@ def test_edge_cases_empty_batch_and_chunking(ia, gpu_ctx):
     ctx.force_generic(False)
     with pytest.raises(ia.IeacheError):
         ctx.eval_batch_device(9, 32, 1, 1, 1)  # unknown circuit kind
+
+
+def test_kogge_stone_adders_decrypt_identically(ia, gpu_ctx):
+    """Opt-in parallel-prefix adders: same plaintext as the reference's ripple adders, fewer levels."""
+    kb, ctx = gpu_ctx(4, 1024)
+    from ieache_amd.tools import bits_to_int
+    vals = [(0xFFFFFFFF, 1), (0x12345678, 0x9ABCDEF0), (0, 0), (0x80000000, 0x80000000)]
+    inp = _inputs(kb, 1, 32, vals, 23)
+    for ks_kind, rc_kind, f in ((ia.CIRC_ADD_KS, ia.CIRC_ADD, lambda a, b: a + b), (ia.CIRC_SUB_KS, ia.CIRC_SUB, lambda a, b: a - b),
+                                (ia.CIRC_RSUB_KS, ia.CIRC_RSUB, lambda a, b: b - a)):
+        st = ia.Stats()
+        out = ctx.eval_batch(ks_kind, 32, inp, st)
+        ref = ctx.eval_batch(rc_kind, 32, inp)
+        assert st.levels == 13
+        assert np.array_equal(kb.dec(out), kb.dec(ref))
+        assert [bits_to_int(d) for d in kb.dec(out)] == [f(a, b) & 0xFFFFFFFF for a, b in vals]
