@@ -206,7 +206,7 @@ constexpr int kTile = 8 * 72;  // double2 elements per tile (9216 B)
 // Forward 512-point transform of the twisted polynomial.
 //   in : x[r] = y_{64r+lane} * exp(i*pi*r/16)  (the lane part tL of the twist is applied here)
 //   out: x[k2] = X[k0 + 8*k1 + 64*k2] with lane = 8*k0 + k1
-template <bool WSYNC, bool XLANE = false>
+template <bool WSYNC, int XLANE = 0>
 __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
@@ -220,7 +220,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
     for (int k = 0; k < 8; k++) x[k] = cmulx<false>(x[k], tA[k]);  // * tL * w512^(lane*k0)
 #pragma unroll
     for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
-    if (XLANE) {
+    if (XLANE & 1) {
         xlane_hi(x, lane);                                          // reg k0 <-> lane bits 3..5: lane = (k0, p0), reg = p1
     } else {
 #pragma unroll
@@ -233,7 +233,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
     dft8<false>(x);                          // over p1 -> k1 ; lane = 8*k0 + p0
 #pragma unroll
     for (int k = 1; k < 8; k++) x[k] = cmulx<false>(x[k], tB[k]);  // * w64^(p0*k1)
-    if (XLANE) {
+    if (XLANE & 2) {
         xlane_lo(x, lane);                                          // reg k1 <-> lane bits 0..2: lane = (k0, k1), reg = p0
     } else {
 #pragma unroll
@@ -250,7 +250,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
 // Inverse of fft512_forward (unnormalised: 512 x), also removing the lane part of the twist:
 //   in : spectrum in the layout fft512_forward produces
 //   out: x[r] = y_{64r+lane} * exp(i*pi*r/16)   (caller multiplies by exp(-i*pi*r/16))
-template <bool WSYNC, bool XLANE = false>
+template <bool WSYNC, int XLANE = 0>
 __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo, blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
@@ -260,7 +260,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int
     dft8<true>(x);  // k2 -> p0 ; lane = (k0, k1)
 #pragma unroll
     for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
-    if (XLANE) {
+    if (XLANE & 2) {
         xlane_lo(x, lane);                                          // back to lane = (k0, p0), reg = k1
     } else {
 #pragma unroll
@@ -273,7 +273,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int
 #pragma unroll
     for (int k = 1; k < 8; k++) x[k] = cmulx<true>(x[k], tB[k]);
     dft8<true>(x);  // k1 -> p1 ; lane = 8*k0 + p0
-    if (XLANE) {
+    if (XLANE & 1) {
         xlane_hi(x, lane);                                          // back to lane = (p1, p0), reg = k0
     } else {
 #pragma unroll
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(128) void k_br_prologue(DevKeys K, WorkDesc W, uint
 // limbs) and inverse-transforms them.  Each forward spectrum is handed to the
 // partner wave through the producing wave's own (then idle) transpose tile.
 // dynamic LDS: sT [2][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32
-template <int L, int BGBIT, bool DIAG, bool WSYNC, bool XLANE = false>
+template <int L, int BGBIT, bool DIAG, bool WSYNC, int XLANE = 0>
 __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf,
                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
                                                            int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
@@ -619,8 +619,10 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
         switch (variant) {
             case 1: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
             case 2: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
-            case 3: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
-            case 4: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, true, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
+            case 3: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
+            case 4: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
+            case 5: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
+            case 6: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true, 2>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
             default: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
         }
     }

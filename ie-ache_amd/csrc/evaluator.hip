@@ -583,7 +583,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->ks_batch_min = value;
     } else if (name == "br_slice" && value >= 1 && value <= 64) {
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 4) {
+    } else if (name == "br_variant" && value >= 0 && value <= 6) {
         d_->br_variant = (int32_t)value;
     } else {
         return false;
