@@ -4,17 +4,22 @@
 // SURVEY.md App. A steps 2-5) with the exact two-limb FP64 negacyclic transform,
 // re-laid out for CDNA4:
 //   * the 512-point complex transform is 8 x 8 x 8: three radix-8 passes done
-//     entirely in registers (8 points per lane), separated by two transposes
-//     through an 8 KiB per-wave LDS tile -- no workgroup barriers, the wave is
-//     its own workgroup;
+//     entirely in registers (8 points per lane), separated by two register<->lane
+//     transposes -- through a padded, bank-conflict-free LDS tile per wave (default)
+//     or cross-lane with v_permlane*_swap / DPP (selectable variants);
 //   * the spectrum stays in registers between the forward transform, the
 //     point-wise multiply-accumulate with BK_i and the inverse transform; BK_i
 //     is stored in exactly the (register, lane) order the forward transform
 //     leaves its output in, so every BK load is one coalesced 1 KiB
-//     global_load_dwordx4 per wave;
-//   * the accumulator (2 x 1024 int32) lives in LDS only because the
-//     X^a rotation needs arbitrary shifts; twiddles are rebuilt from three
-//     per-lane roots of unity instead of tables.
+//     global_load_dwordx4 per wave, issued a batch ahead of its MACs;
+//   * wave w of a gate's workgroup decomposes accumulator polynomial w and owns
+//     output polynomial w's two limb sums (the 256 architectural VGPRs do not
+//     hold all four next to a transform); spectra cross waves through LDS;
+//   * the CMux step index is the OUTER loop of the evaluator: one launch
+//     advances every gate of a chunk by a slice of steps, so all resident
+//     workgroups read the same BK blocks while they are hot in the XCD's L2;
+//   * the accumulator (2 x 1024 int32) lives in LDS only because the X^a
+//     rotation needs arbitrary shifts; twiddles come from a 9 KiB LDS table.
 #include "blind_rotate_w64.h"
 
 #include <cstdio>
@@ -37,7 +42,6 @@ template <bool INV>
 __device__ __forceinline__ double2 rot90(double2 z) {
     return INV ? make_double2(-z.y, z.x) : make_double2(z.y, -z.x);
 }
-__device__ __forceinline__ double2 csqr(double2 a) { return make_double2(fma(a.x, a.x, -a.y * a.y), (a.x + a.x) * a.y); }
 // a * b  or  a * conj(b)
 template <bool CONJ>
 __device__ __forceinline__ double2 cmulx(double2 a, double2 b) {
