@@ -344,8 +344,10 @@ __global__ __launch_bounds__(kKsThreads) void k_keyswitch_vec(DevKeys K, WorkDes
 // digit selects: 3 x 2.5 KB x N x t / G bytes per gate instead of ~0.75 x 2.5 KB x N x t.
 // One wave per 64 int4 columns of a row (3 waves at n=630), each lane owning one column
 // for all G gates, so no partial sums cross waves.  The t digits of a'_i are packed into
-// one word per gate, pulled into SGPRs once per i; selection is scalar branching, and
-// subtraction mod 2^32 commutes, so the result is bit-identical to the other kernels.
+// one word per gate, pulled into SGPRs once per i; the digit (wave-uniform) indexes a 4-row
+// register table {0, r1, r2, r3} through the SGPR-indexed VGPR mode (s_set_gpr_idx), which is
+// 3x cheaper than v_cndmask chains or scalar branches.  Subtraction mod 2^32 commutes, so the
+// result is bit-identical to the other kernels.
 // LDS: dw [G][N] u16 | bprime [G]
 template <int G>
 __global__ __launch_bounds__(256) void k_keyswitch_batch(DevKeys K, WorkDesc W, const Torus32* ext, Torus32* flat_out,
@@ -384,8 +386,6 @@ __global__ __launch_bounds__(256) void k_keyswitch_batch(DevKeys K, WorkDesc W, 
     // Walk i (the extracted coefficient), then its t digits.  The packed digits of a'_i of all
     // G gates are pulled into SGPRs once per i.  Candidate rows are requested two positions
     // ahead into a ring of three named row sets (the walk is latency-bound otherwise).
-    // Selection is branch-free: a digit picks one of the three rows (or nothing) through
-    // wave-uniform v_cndmask masks.
     const size_t npos = (size_t)N * t;
 #define KS_LOAD(A, B, C, POS)                                        \
     {                                                                \
@@ -397,13 +397,15 @@ __global__ __launch_bounds__(256) void k_keyswitch_batch(DevKeys K, WorkDesc W, 
         C = row_[3 * rowpitch];                                      \
     }
 #define KS_USE(A, B, C, SH)                                                        \
-    _Pragma("unroll") for (int g = 0; g < G; g++) {                                \
-        const uint32_t d_ = (dg[g] >> (SH)) & mask;                                \
-        const bool is1 = d_ == 1, is2 = d_ == 2, is3 = d_ == 3;                    \
-        acc[g].x -= is1 ? A.x : (is2 ? B.x : (is3 ? C.x : 0));                     \
-        acc[g].y -= is1 ? A.y : (is2 ? B.y : (is3 ? C.y : 0));                     \
-        acc[g].z -= is1 ? A.z : (is2 ? B.z : (is3 ? C.z : 0));                     \
-        acc[g].w -= is1 ? A.w : (is2 ? B.w : (is3 ? C.w : 0));                     \
+    {                                                                              \
+        const int32_t tab_[16] = {0, 0, 0, 0, A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z, C.w}; \
+        _Pragma("unroll") for (int g = 0; g < G; g++) {                            \
+            const uint32_t d_ = ((dg[g] >> (SH)) & mask) * 4;  /* uniform: SGPR-indexed register read */ \
+            acc[g].x -= tab_[d_ + 0];                                              \
+            acc[g].y -= tab_[d_ + 1];                                              \
+            acc[g].z -= tab_[d_ + 2];                                              \
+            acc[g].w -= tab_[d_ + 3];                                              \
+        }                                                                          \
     }
     int4 a1, a2, a3, b1, b2, b3, c1, c2, c3;
     KS_LOAD(a1, a2, a3, 0)
@@ -488,7 +490,7 @@ struct Evaluator::Impl {
     size_t br_lds = 0, ks_lds = 0, ksv_lds = 0;
     int ks_nld = 0;  // dwordx4 loads per KSK row per wave; 0 = use the scalar kernel
     bool ks_batch_ok = false;     // gate-batched key switch usable (base == 4, digits fit 16 bits, columns fit 8 waves)
-    int64_t ks_batch_min = 6144;  // use it from this many gate instances per launch (one workgroup walk takes ~6 ms)
+    int64_t ks_batch_min = 4096;  // use it from this many gate instances per launch (one workgroup walk takes ~5 ms)
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
     int32_t br_variant = w64::default_variant();
 };

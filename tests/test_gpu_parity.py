@@ -313,7 +313,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     rng = np.random.default_rng(3)
     bits = rng.integers(0, 2, size=(2, 2304)).astype(np.uint8)
     a, b = kb.enc(bits[0], 41), kb.enc(bits[1], 42)
-    ref = ctx.gates(ia.GATE_AND, a, b)                     # defaults: slice 16, per-gate key switch (< 6144 gates)
+    ref = ctx.gates(ia.GATE_AND, a, b)                     # defaults: slice 16, per-gate key switch (< 4096 gates)
     assert np.array_equal(kb.dec(ref), bits[0] & bits[1])
     for i in (0, 1, 2303):
         assert np.array_equal(kb.ck.gate("and", a[i], b[i]), ref[i])
@@ -329,7 +329,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
     ctx.set_option("ks_batch_min", 1)                      # gate-batched key switch even for tiny launches
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:37], b[:37]), ref[:37])  # ragged last group of 16
-    ctx.set_option("ks_batch_min", 6144)
+    ctx.set_option("ks_batch_min", 4096)
     ctx.force_generic(True)
     assert ctx.kernel_variant == "generic-radix2"
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
