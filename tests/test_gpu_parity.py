@@ -375,3 +375,25 @@ def test_kogge_stone_adders_decrypt_identically(ia, gpu_ctx):
         assert st.levels == 13
         assert np.array_equal(kb.dec(out), kb.dec(ref))
         assert [bits_to_int(d) for d in kb.dec(out)] == [f(a, b) & 0xFFFFFFFF for a, b in vals]
+
+
+def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
+    """A wider bit-exact sweep at n=630, N=1024: random gate types and operands, including
+    operands that are themselves bootstrapped outputs and NOT-ed inputs (the oracle takes ~0.4 s/gate)."""
+    z = np.load(os.path.join(G, "full_gate_kat.npz"))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(int(v) for v in z["seed"]))
+    rng = np.random.default_rng(77)
+    n_g = 24
+    bits = rng.integers(0, 2, size=(2, n_g)).astype(np.uint8)
+    a, b = kb.enc(bits[0], 51), kb.enc(bits[1], 52)
+    a[::3] = (0 - a[::3].astype(np.int64)).astype(np.int32)      # bootsNOT of every third operand
+    abits = bits[0].copy()
+    abits[::3] ^= 1
+    first = ctx.gates(ia.GATE_XOR, a, b)                          # level 1
+    second = ctx.gates(ia.GATE_AND, first, b)                     # level 2 consumes bootstrapped outputs
+    assert np.array_equal(kb.dec(first), abits ^ bits[1])
+    assert np.array_equal(kb.dec(second), (abits ^ bits[1]) & bits[1])
+    for i in range(n_g):
+        r1 = kb.ck.gate("xor", a[i], b[i])
+        assert np.array_equal(r1, first[i]), i
+        assert np.array_equal(kb.ck.gate("and", r1, b[i]), second[i]), i
