@@ -397,3 +397,32 @@ def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
         r1 = kb.ck.gate("xor", a[i], b[i])
         assert np.array_equal(r1, first[i]), i
         assert np.array_equal(kb.ck.gate("and", r1, b[i]), second[i]), i
+
+
+def test_full_config_add16_batch4096_decrypts(ia, gpu_ctx):
+    """BASELINE.json configs[1] at full size (n=630, 4096 ciphertext pairs, 327 680 bootstraps): every one
+    of the 4096 sums must decrypt to a+b mod 2^16 (the size-independent property), and a sampled
+    expression must equal the oracle bit for bit."""
+    z = np.load(os.path.join(G, "full_gate_kat.npz"))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(int(v) for v in z["seed"]))
+    from ieache_amd.tools import bits_to_int
+    rng = np.random.default_rng(4096)
+    B, bits = 4096, 16
+    info = ia.circuit_info(ia.CIRC_ADD, bits)
+    inb = rng.integers(0, 2, size=(B, info.n_inputs), dtype=np.uint8)
+    inb[:, 2 * bits:] = 0                                   # carry word encrypts 0 (alice.c:147-149)
+    inb[0, :2 * bits] = 1                                   # 0xFFFF + 0xFFFF: carries through every bit
+    inb[1, :2 * bits] = 0
+    inp = kb.enc(inb, 404)
+    st = ia.Stats()
+    out = ctx.eval_batch(ia.CIRC_ADD, bits, inp, st)
+    assert st.bootstraps == 80 * B and st.levels == 48
+    dec = kb.dec(out)
+    w = 1 << np.arange(bits, dtype=np.int64)
+    a = (inb[:, :bits] * w).sum(1)
+    b = (inb[:, bits:2 * bits] * w).sum(1)
+    got = (dec.astype(np.int64) * w).sum(1)
+    assert np.array_equal(got, (a + b) & 0xFFFF)
+    e = 1234
+    s, _ = kb.ck.add(inp[e, :bits], inp[e, bits:2 * bits], inp[e, 2 * bits:2 * bits + 1], bits)  # 80 oracle bootstraps
+    assert np.array_equal(s, out[e])
