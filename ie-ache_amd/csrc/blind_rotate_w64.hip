@@ -292,6 +292,62 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int
     dft8<true>(x);  // k0 -> r
 }
 
+// Two inverse transforms (the lo and hi limb sums of one output polynomial) interleaved in one
+// instruction stream through ONE tile: the DS instructions of a wave execute in order, so as
+// long as each [write, read] pair of one transform is issued whole, the other transform's
+// butterflies run while that round trip is in flight.  (Alone, a wave spends ~2/3 of a
+// transform waiting on its four LDS round trips.)
+template <bool WSYNC>
+__device__ __forceinline__ void fft512_inverse_pair(double2 (&x)[8], double2 (&y)[8], double2* sT, int lane,
+                                                    const LaneRoots& R) {
+    const int hi = lane >> 3, lo = lane & 7;
+    const int own = hi * 9 + lo, blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
+    double2 tA[8], tB[8];
+#pragma unroll
+    for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
+    dft8<true>(x);
+#pragma unroll
+    for (int q = 0; q < 8; q++) sT[rd + q] = x[q];
+    tile_sync<WSYNC>();
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = sT[blk + 9 * k];          // x round trip 1 in flight ...
+    dft8<true>(y);                                                // ... under y's first pass
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
+#pragma unroll
+    for (int q = 0; q < 8; q++) sT[rd + q] = y[q];               // issued after x's reads: in-order LDS keeps them apart
+    tile_sync<WSYNC>();
+#pragma unroll
+    for (int k = 0; k < 8; k++) y[k] = sT[blk + 9 * k];          // y round trip 1 ...
+#pragma unroll
+    for (int k = 1; k < 8; k++) x[k] = cmulx<true>(x[k], tB[k]);
+    dft8<true>(x);                                                // ... under x's second pass
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p1 = 0; p1 < 8; p1++) sT[blk + 9 * p1] = x[p1];
+    tile_sync<WSYNC>();
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) x[k0] = sT[own + 72 * k0];    // x round trip 2 ...
+#pragma unroll
+    for (int k = 1; k < 8; k++) y[k] = cmulx<true>(y[k], tB[k]);
+    dft8<true>(y);                                                // ... under y's second pass
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p1 = 0; p1 < 8; p1++) sT[blk + 9 * p1] = y[p1];
+    tile_sync<WSYNC>();
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0++) y[k0] = sT[own + 72 * k0];    // y round trip 2 ...
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = cmulx<true>(x[k], tA[k]);
+    dft8<true>(x);                                                // ... under x's last pass
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) y[k] = cmulx<true>(y[k], tA[k]);
+    dft8<true>(y);
+    tile_sync<WSYNC>();  // the tile may be reused by the caller
+}
+
 // exp(i*pi*r/16), r = 0..7: the register part of the twist
 __device__ __forceinline__ double2 twist_reg(int r) {
     constexpr double C[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
@@ -507,24 +563,21 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
             IEACHE_STAMP(5)
         }
         // back to coefficients, round, recombine the two limbs, accumulate into polynomial `wave`
-        uint32_t lo0[8], lo1[8];
+        if (XLANE == 0) {
+            fft512_inverse_pair<WSYNC>(s[0], s[1], sT, lane, R);
+        } else {
+            fft512_inverse<WSYNC, XLANE>(s[0], sT, lane, R);
+            fft512_inverse<WSYNC, XLANE>(s[1], sT, lane, R);
+        }
 #pragma unroll
-        for (int limb = 0; limb < 2; limb++) {
-            fft512_inverse<WSYNC, XLANE>(s[limb], sT, lane, R);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const double2 z = cmulx<true>(s[limb][r], untwist_reg(r));
-                const uint32_t i0 = (uint32_t)__double2loint(z.x + kMagic);
-                const uint32_t i1 = (uint32_t)__double2loint(z.y + kMagic);
-                if (limb == 0) {
-                    lo0[r] = i0;
-                    lo1[r] = i1;
-                } else {
-                    const int32_t j = 64 * r + lane;
-                    accw[j] = (int32_t)((uint32_t)accw[j] + lo0[r] + (i0 << 16));
-                    accw[j + kM] = (int32_t)((uint32_t)accw[j + kM] + lo1[r] + (i1 << 16));
-                }
-            }
+        for (int r = 0; r < 8; r++) {
+            const double2 zl = cmulx<true>(s[0][r], untwist_reg(r));
+            const double2 zh = cmulx<true>(s[1][r], untwist_reg(r));
+            const uint32_t l0 = (uint32_t)__double2loint(zl.x + kMagic), l1 = (uint32_t)__double2loint(zl.y + kMagic);
+            const uint32_t h0 = (uint32_t)__double2loint(zh.x + kMagic), h1 = (uint32_t)__double2loint(zh.y + kMagic);
+            const int32_t j = 64 * r + lane;
+            accw[j] = (int32_t)((uint32_t)accw[j] + l0 + (h0 << 16));
+            accw[j + kM] = (int32_t)((uint32_t)accw[j + kM] + l1 + (h1 << 16));
         }
         IEACHE_STAMP(6)
         __syncthreads();
