@@ -1,5 +1,5 @@
-// Wave-per-gate blind rotation specialised for N=1024, k=1, l=3, Bgbit=7
-// (libtfhe's default 128-bit gate-bootstrapping set).  See blind_rotate_w64.hip.
+// Two-waves-per-gate blind rotation specialised for N=1024, k=1 and libtfhe's two default
+// gate-bootstrapping sets: l=3, Bgbit=7 (>= v1.1) and l=2, Bgbit=10 (v1.0).  See blind_rotate_w64.hip.
 #pragma once
 #include "device_common.h"
 

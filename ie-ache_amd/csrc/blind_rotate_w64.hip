@@ -603,7 +603,11 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 
 }  // namespace
 
-bool supported(const Params& p) { return p.N == kN && p.k == 1 && p.l == 3 && p.Bgbit == 7 && p.n <= 4096; }
+// N=1024, k=1 with either libtfhe parameter set: l=3/Bgbit=7 (>= v1.1, "128-bit") or l=2/Bgbit=10
+// (v1.0 and the paper's 78 MiB keys).  Exactness margin for the latter: 4 rows x 1024 x 512 x 2^15 < 2^37.
+bool supported(const Params& p) {
+    return p.N == kN && p.k == 1 && ((p.l == 3 && p.Bgbit == 7) || (p.l == 2 && p.Bgbit == 10)) && p.n <= 4096;
+}
 
 size_t spectrum_elems(const Params& p) { return (size_t)p.n * p.kpl() * 4 * kM; }
 
@@ -647,6 +651,21 @@ static void diag_report(hipStream_t stream, int64_t items, int32_t nsteps) {
     }
 }
 
+template <int L, int BGBIT>
+static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream_t stream, const DevKeys& K, const double2* d_bkf,
+                         const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e) {
+    unsigned long long* const nodiag = nullptr;
+    switch (variant) {
+        case 1: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
+        case 2: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
+        case 3: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
+        case 4: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
+        case 5: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
+        case 6: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 2>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
+        default: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
+    }
+}
+
 int32_t default_variant() {
     static const int32_t v = getenv("IEACHE_BR_VARIANT") ? atoi(getenv("IEACHE_BR_VARIANT")) : 0;
     return v;
@@ -673,21 +692,18 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
         Torus32* e = (i1 == nsteps) ? ext : nullptr;  // the last slice extracts instead of storing the accumulator
         launches++;
-        switch (variant) {
-            case 1: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
-            case 2: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
-            case 3: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
-            case 4: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, true, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
-            case 5: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
-            case 6: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true, 2>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
-            default: hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr); break;
-        }
+        if (p.l == 3)
+            launch_slice<3, 7>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e);
+        else
+            launch_slice<2, 10>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e);
     }
     if (variant == 1 || variant == 4) diag_report(stream, items, nsteps);
     if (nsteps == 0 && ext) {
         // degenerate (steps == 0): extraction straight from the initial accumulator
-        hipLaunchKernelGGL((k_blind_rotate_w2<3, 7, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext,
-                           (unsigned long long*)nullptr);
+        if (p.l == 3)
+            launch_slice<3, 7>(0, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext);
+        else
+            launch_slice<2, 10>(0, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext);
     }
     if (dbg_acc)
         (void)hipMemcpyAsync(dbg_acc, st_acc, (size_t)items * 2 * kN * 4, hipMemcpyDeviceToDevice, stream);

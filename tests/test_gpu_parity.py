@@ -426,3 +426,28 @@ def test_full_config_add16_batch4096_decrypts(ia, gpu_ctx):
     e = 1234
     s, _ = kb.ck.add(inp[e, :bits], inp[e, bits:2 * bits], inp[e, 2 * bits:2 * bits + 1], bits)  # 80 oracle bootstraps
     assert np.array_equal(s, out[e])
+
+
+def test_old_libtfhe_parameter_set_on_fast_kernel(ia, gpu_ctx):
+    """libtfhe 1.0's default set (l=2, Bgbit=10 -- the paper's 78 MiB keys) also runs on the
+    wave-per-polynomial kernel; parameters always come from the key header."""
+    kb, ctx = gpu_ctx(12, 1024, l=2, Bgbit=10, lwe_alpha_min=2.44e-5, tlwe_alpha_min=7.18e-9)
+    assert "radix8" in ctx.kernel_variant
+    a_bits = np.array([0, 0, 1, 1] * 4, dtype=np.uint8)
+    b_bits = np.array([0, 1, 0, 1] * 4, dtype=np.uint8)
+    a, b = kb.enc(a_bits, 61), kb.enc(b_bits, 62)
+    out = ctx.gates(ia.GATE_XOR, a, b)
+    assert np.array_equal(kb.dec(out), a_bits ^ b_bits)
+    for i in range(16):
+        assert np.array_equal(kb.ck.gate("xor", a[i], b[i]), out[i]), i
+    x = kb.enc([1, 0, 1], 63)
+    acc = ctx.debug_blind_rotate(x, 3)
+    for i in range(3):
+        bara, barb = kb.ck.modswitch(x[i])
+        ref = kb.ck.blind_rotate_init(barb)
+        for s_ in range(3):
+            ref = kb.ck.blind_rotate_step(ref, s_, bara[s_])
+        assert np.array_equal(ref, acc[i])
+    ctx.force_generic(True)
+    assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), out)
+    ctx.force_generic(False)
