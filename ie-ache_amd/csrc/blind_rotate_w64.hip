@@ -601,6 +601,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
     }
 }
 
+
 }  // namespace
 
 // N=1024, k=1 with either libtfhe parameter set: l=3/Bgbit=7 (>= v1.1, "128-bit") or l=2/Bgbit=10
