@@ -203,11 +203,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32 torus (exact two-limb f64 FFT inside the external product)",
+            "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": config_name, "circuit": "%s%d" % (args.workload.rstrip("0123456789"), bits),
                        "batch_per_gpu": batch, "bootstraps_per_expr": int(info.bootstraps), "levels": int(info.depth),
-                       "params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2", "parallelism": "batch-sharded x%d" % world,
+                       "params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2",
+                       "arithmetic": "Torus32 = int32 with wraparound; the negacyclic products inside the external product run as an exact two-limb f64 transform", "parallelism": "batch-sharded x%d" % world,
                        "kernel": ctx.kernel_variant, "key_broadcast_s": round(t_bcast, 4)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
