@@ -144,15 +144,17 @@ def main():
     # correctness of what is being timed: decrypt a few expressions
     if args.warmup == 0:
         step()
-    chk = min(batch, 8)
-    dec = tools.decrypt_bits(p, lwe_key, d_out[:chk, :, :p.n + 1].cpu().numpy())
-    for e in range(chk):
-        a = tools.bits_to_int(inb[e, :bits])
-        b = tools.bits_to_int(inb[e, bits:2 * bits])
-        exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 3: (b - a) % (1 << bits), 4: a * b}.get(kind)
-        if kind == 5:
-            exp = (a * b + tools.bits_to_int(inb[e, 2 * bits + 32:])) % (1 << (2 * bits))
-        assert tools.bits_to_int(dec[e]) == exp, "rank %d: expression %d decrypts wrong" % (rank, e)
+    # every expression of the batch must decrypt to the integer result (P1 at full size)
+    for s0 in range(0, batch, 512):
+        e0 = min(batch, s0 + 512)
+        dec = tools.decrypt_bits(p, lwe_key, d_out[s0:e0, :, :p.n + 1].cpu().numpy())
+        for e in range(s0, e0):
+            a = tools.bits_to_int(inb[e, :bits])
+            b = tools.bits_to_int(inb[e, bits:2 * bits])
+            exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 3: (b - a) % (1 << bits), 4: a * b}.get(kind)
+            if kind == 5:
+                exp = (a * b + tools.bits_to_int(inb[e, 2 * bits + 32:])) % (1 << (2 * bits))
+            assert tools.bits_to_int(dec[e - s0]) == exp, "rank %d: expression %d decrypts wrong" % (rank, e)
 
     stats = ia.Stats()
     if world > 1:
