@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearse the N>1 flow with CPU collectives (ranks may then share one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +93,9 @@ def main():
     from ieache_amd import tools
 
     from ieache_amd import parallel
-    rank, world, local_rank, dist = parallel.init_distributed("nccl")
+    rank, world, local_rank, dist = parallel.init_distributed(args.backend)
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())  # rehearsal: ranks wrap around the GPUs present
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -108,7 +112,8 @@ def main():
     keys = tools.keygen_raw(p, (314, 1592, 657)) if rank == 0 else None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    d_bk, d_ksk, d_key = parallel.broadcast_cloud_key(p, keys, dev, dist)
+    bdev = dev if args.backend == "nccl" else torch.device("cpu")
+    d_bk, d_ksk, d_key = (t.to(dev) for t in parallel.broadcast_cloud_key(p, keys, bdev, dist))
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0 if world > 1 else 0.0
     lwe_key = d_key.cpu().numpy()
@@ -168,7 +173,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
