@@ -387,7 +387,8 @@ __global__ __launch_bounds__(64) void k_bk_to_spectrum_w64(const Torus32* bk_raw
             const int32_t lo0 = (int16_t)(v0 & 0xFFFF), lo1 = (int16_t)(v1 & 0xFFFF);
             const int32_t e0 = limb ? (int32_t)(((int64_t)v0 - lo0) >> 16) : lo0;
             const int32_t e1 = limb ? (int32_t)(((int64_t)v1 - lo1) >> 16) : lo1;
-            x[r] = cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            x[r] = r == 0 ? make_double2((double)e0, (double)e1)  // exp(0) = 1: nothing to multiply
+                            : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
         }
         fft512_forward<true>(x, sT, lane, R);
         double2* dst = bkf + ((irow * 4 + c * 2 + limb) * 8) * 64 + lane;
@@ -511,7 +512,8 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = (int32_t)((v0[r] >> sh) & maskBg) - (int32_t)halfBg;
                 const int32_t e1 = (int32_t)((v1[r] >> sh) & maskBg) - (int32_t)halfBg;
-                x[r] = cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = r == 0 ? make_double2((double)e0, (double)e1)  // exp(0) = 1: nothing to multiply
+                            : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
             // BK loads are issued well ahead of their use (each is an L2 round trip of ~700 cycles):
             //   bA = own row, limb 0      before the transform
@@ -571,8 +573,8 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const double2 zl = cmulx<true>(s[0][r], untwist_reg(r));
-            const double2 zh = cmulx<true>(s[1][r], untwist_reg(r));
+            const double2 zl = r == 0 ? make_double2(s[0][0].x * (1.0 / 512.0), s[0][0].y * (1.0 / 512.0)) : cmulx<true>(s[0][r], untwist_reg(r));
+            const double2 zh = r == 0 ? make_double2(s[1][0].x * (1.0 / 512.0), s[1][0].y * (1.0 / 512.0)) : cmulx<true>(s[1][r], untwist_reg(r));
             const uint32_t l0 = (uint32_t)__double2loint(zl.x + kMagic), l1 = (uint32_t)__double2loint(zl.y + kMagic);
             const uint32_t h0 = (uint32_t)__double2loint(zh.x + kMagic), h1 = (uint32_t)__double2loint(zh.y + kMagic);
             const int32_t j = 64 * r + lane;
