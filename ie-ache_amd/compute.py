@@ -4,7 +4,8 @@
 1219-1297 and 1300-1327: write operator.txt, run the evaluator on the files in
 the working directory, apply the 64-sample failure rule.  The reference does
 subprocess.call("./cloud"); here the same contract is one ctypes call into
-libieache.so (or the `cloud` executable built next to it, use_subprocess=True).
+libieache.so (or the `cloud` executable built next to it, use_subprocess=True; or a
+running `cloudd` that already holds the key on the GPU, daemon_socket=...).
 """
 import os
 import shutil
@@ -20,7 +21,7 @@ FAILURE_SIZE = 162304
 _PKG = os.path.dirname(os.path.abspath(__file__))
 
 
-def compute(operator, workdir=".", ctx=None, use_subprocess=False, failure_size=FAILURE_SIZE):
+def compute(operator, workdir=".", ctx=None, use_subprocess=False, failure_size=FAILURE_SIZE, daemon_socket=None):
     """operator: 1 add, 2 subtract, 3 or 4 multiply (both write "4", :1256-1274).
 
     Returns (exit_code, answer_size, ok).  ok is False when answer.data holds
@@ -33,7 +34,12 @@ def compute(operator, workdir=".", ctx=None, use_subprocess=False, failure_size=
     with open(os.path.join(workdir, "operator.txt"), "w") as o:
         o.write(code)
     t0 = time.perf_counter()
-    if use_subprocess:
+    if daemon_socket is not None:
+        from . import daemon
+        rc, _log = daemon.run_dir(daemon_socket, workdir)
+        if rc < 0:
+            raise RuntimeError("cloudd: %s" % _log)
+    elif use_subprocess:
         rc = subprocess.call([os.path.join(_PKG, "cloud")], cwd=workdir)
     elif ctx is not None:
         rc = ctx.cloud_run(workdir)
@@ -46,7 +52,8 @@ def compute(operator, workdir=".", ctx=None, use_subprocess=False, failure_size=
     return rc, ans_size, ans_size > failure_size
 
 
-def compute_final(operator, workdir=".", flip=True, ctx=None, use_subprocess=False, failure_size=FAILURE_SIZE):
+def compute_final(operator, workdir=".", flip=True, ctx=None, use_subprocess=False, failure_size=FAILURE_SIZE,
+                  daemon_socket=None):
     """Second stage of a 3-operand expression (:1300-1327): cloud.data holds the
     third operand; combine it with the previous answer.data and run again."""
     cloud = os.path.join(workdir, "cloud.data")
@@ -59,4 +66,5 @@ def compute_final(operator, workdir=".", flip=True, ctx=None, use_subprocess=Fal
         with open(answer, "rb") as a, open(cloud, "ab") as c:
             shutil.copyfileobj(a, c, 8192)
     os.remove(answer)
-    return compute(operator, workdir, ctx=ctx, use_subprocess=use_subprocess, failure_size=failure_size)
+    return compute(operator, workdir, ctx=ctx, use_subprocess=use_subprocess, failure_size=failure_size,
+                   daemon_socket=daemon_socket)

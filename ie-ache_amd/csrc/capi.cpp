@@ -14,6 +14,7 @@
 #include "circuit.h"
 #include "cloud_run.h"
 #include "codec.h"
+#include "daemon.h"
 #include "evaluator.h"
 #include "tfhe_host.h"
 
@@ -570,6 +571,72 @@ int ieache_verif(const char* secret_key_path, const char* nbit_key_path, const c
             for (int w = 0; w < 9; w++) words9[w] = dec_word(key, 2 + w);
         return 0;
     });
+}
+
+// ---- 5. resident-key daemon ----
+int64_t ieache_serve(const char* socket_path, const char* cloud_key_path, const char* nbit_key_path, int device,
+                     int64_t max_requests) {
+    int64_t served = 0;
+    const int rc = guarded([&] {
+        if (!socket_path || !cloud_key_path) return fail(IEACHE_EINVAL, "null argument");
+        DaemonConfig cfg;
+        cfg.socket_path = socket_path;
+        cfg.cloud_key_path = cloud_key_path;
+        if (nbit_key_path) cfg.nbit_key_path = nbit_key_path;
+        cfg.device = device;
+        cfg.max_requests = max_requests;
+        served = daemon_serve(cfg);
+        return 0;
+    });
+    return rc != 0 ? rc : served;
+}
+
+static int client_call(const char* socket_path, uint32_t op, const void* payload, size_t len, DaemonReply* reply) {
+    return guarded([&] {
+        if (!socket_path) return fail(IEACHE_EINVAL, "null socket path");
+        *reply = daemon_request(socket_path, op, payload, len);
+        if (reply->rc < 0) g_err = reply->log;  // the daemon's message for IEACHE_E*
+        return (int)reply->rc;
+    });
+}
+
+int ieache_client_ping(const char* socket_path) {
+    DaemonReply r;
+    return client_call(socket_path, DAEMON_PING, nullptr, 0, &r);
+}
+
+int ieache_client_run_dir(const char* socket_path, const char* workdir) {
+    if (!workdir) return fail(IEACHE_EINVAL, "null workdir");
+    DaemonReply r;
+    const int rc = client_call(socket_path, DAEMON_RUN_DIR, workdir, strlen(workdir), &r);
+    if (rc >= 0) fputs(r.log.c_str(), stdout);  // the chatter main() of cloud.c prints
+    return rc;
+}
+
+int ieache_client_run_data(const char* socket_path, int operator_code, const void* cloud_data, size_t cloud_data_len,
+                           void* answer, size_t answer_cap, size_t* answer_len) {
+    if (!cloud_data && cloud_data_len) return fail(IEACHE_EINVAL, "null cloud.data");
+    DaemonReply r;
+    std::vector<unsigned char> payload;
+    const int prc = guarded([&] {
+        payload.resize(4 + cloud_data_len);
+        const int32_t op = operator_code;
+        memcpy(payload.data(), &op, 4);
+        if (cloud_data_len) memcpy(payload.data() + 4, cloud_data, cloud_data_len);
+        return 0;
+    });
+    if (prc != 0) return prc;
+    const int rc = client_call(socket_path, DAEMON_RUN_DATA, payload.data(), payload.size(), &r);
+    if (rc < 0) return rc;
+    if (answer_len) *answer_len = r.data.size();
+    if (r.data.size() > answer_cap || (!answer && !r.data.empty())) return fail(IEACHE_EINVAL, "answer buffer too small");
+    if (!r.data.empty()) memcpy(answer, r.data.data(), r.data.size());
+    return rc;
+}
+
+int ieache_client_shutdown(const char* socket_path) {
+    DaemonReply r;
+    return client_call(socket_path, DAEMON_SHUTDOWN, nullptr, 0, &r);
 }
 
 }  // extern "C"

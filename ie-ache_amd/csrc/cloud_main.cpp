@@ -1,12 +1,25 @@
 // `cloud` executable shim: same invocation as the reference binary
 // (subprocess.call("./cloud"), Cloud/dragonfly_cipher_cloud.py:1233): no
 // arguments, files in the current directory, exit code 0 or 126.
+// With IEACHE_DAEMON=<socket> the work is handed to a running `cloudd`, which
+// already holds the cloud key on the GPU; if none answers, this process does
+// the run itself (same GPU path, plus the key load).
+#include <climits>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/ieache.h"
 
 int main(int argc, char** argv) {
     const char* dir = argc > 1 ? argv[1] : ".";
+    if (const char* sock = getenv("IEACHE_DAEMON")) {
+        char abs_dir[PATH_MAX];
+        if (realpath(dir, abs_dir)) {  // the daemon has its own cwd
+            const int rc = ieache_client_run_dir(sock, abs_dir);
+            if (rc >= 0) return rc;
+            fprintf(stderr, "cloud: daemon: %s; running in-process\n", ieache_last_error());
+        }
+    }
     const int rc = ieache_cloud_run(dir);
     if (rc < 0) {
         fprintf(stderr, "cloud: %s\n", ieache_last_error());

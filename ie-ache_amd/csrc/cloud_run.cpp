@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <random>
 #include <vector>
 
@@ -43,34 +44,59 @@ int32_t decrypt_word(const Params& p, const int32_t* key, const Torus32* samples
 }
 }  // namespace
 
-int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* report, int device) {
+int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* report, int device, FILE* log) {
+    if (!log) log = stdout;
     const std::string d = dir.empty() ? std::string(".") : dir;
     auto path = [&](const char* name) { return d + "/" + name; };
-    printf("Reading the key...\n");
+    fprintf(log, "Reading the key...\n");
     // cloud.c:656-663
     CloudKeyData ck;
-    Evaluator* eval = shared_eval;
     std::unique_ptr<Evaluator> owned;
-    if (!eval) {
-        load_cloud_key(path("cloud.key"), &ck);
-    }
+    if (!shared_eval) load_cloud_key(path("cloud.key"), &ck);
     SecretKeyData nbit;
     load_secret_key(path("nbit.key"), &nbit, /*with_cloud=*/false);
-    const Params p = eval ? eval->params() : ck.p;
+    FileCloser data{fopen(path("cloud.data").c_str(), "rb")};  // cloud.c:703-705
+    if (!data.f) throw CodecError("cannot open cloud.data");
+    int32_t int_op = 0;  // cloud.c:769-773
+    {
+        std::ifstream in(path("operator.txt"));
+        in >> int_op;
+    }
+    FileCloser ans{nullptr};
+    CloudRunIO io;
+    io.params = shared_eval ? shared_eval->params() : ck.p;
+    io.nbit = &nbit;
+    io.cloud_data = data.f;
+    io.op = int_op;
+    io.open_answer = [&]() -> FILE* {  // cloud.c:809, after the inputs have been read
+        ans.f = fopen(path("answer.data").c_str(), "wb");
+        if (!ans.f) throw CodecError("cannot create answer.data");
+        return ans.f;
+    };
+    io.stats_path = path("averagestandard.txt");
+    io.log = log;
+    return cloud_run_io(io, [&]() -> Evaluator* {
+        if (shared_eval) return shared_eval;
+        owned.reset(new Evaluator(ck.p, device));
+        owned->load_keys_host(ck.bk.data(), ck.ksk.data());
+        return owned.get();
+    }, report);
+}
+
+int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_eval, CloudRunReport* report) {
+    FILE* const log = io.log ? io.log : stdout;
+    const SecretKeyData& nbit = *io.nbit;
+    const Params p = io.params;
     const Params& np = nbit.p;
     if (np.n != p.n) throw CodecError("nbit.key and cloud.key disagree on the LWE dimension");
     const int32_t n = p.n;
     const size_t S = (size_t)n + 1, WORD = 32 * S;
 
     // cloud.c:703-766: 22 arrays of 32 samples
-    printf("Reading input 1...\n");
+    fprintf(log, "Reading input 1...\n");
     std::vector<Torus32> data(22 * WORD);
-    {
-        FileCloser f{fopen(path("cloud.data").c_str(), "rb")};
-        if (!f.f) throw CodecError("cannot open cloud.data");
-        read_lwe_samples(f.f, n, 22 * 32, data.data());
-    }
-    printf("Reading input 2...\n");
+    read_lwe_samples(io.cloud_data, n, 22 * 32, data.data());
+    fprintf(log, "Reading input 2...\n");
     const Torus32* neg1 = data.data();
     const Torus32* bit1 = data.data() + WORD;
     const Torus32* opnd1 = data.data() + 2 * WORD;    // ciphertext1..8
@@ -81,21 +107,17 @@ int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* re
     const int32_t int_bit1 = decrypt_word(np, nbit.lwe_key.data(), bit1);
     const int32_t int_bit2 = decrypt_word(np, nbit.lwe_key.data(), bit2);
 
-    printf("Reading operation code...\n");
-    int32_t int_op = 0;  // cloud.c:769-773
-    {
-        std::ifstream in(path("operator.txt"));
-        in >> int_op;
-    }
+    fprintf(log, "Reading operation code...\n");
+    const int32_t int_op = io.op;
     int32_t int_negative1 = decrypt_word(np, nbit.lwe_key.data(), neg1);  // :780-785
-    printf("%d => negative1\n", int_negative1);
+    fprintf(log, "%d => negative1\n", int_negative1);
     if (int_negative1 == 2) int_negative1 = 1;  // :787-789
     const int32_t int_negative2 = decrypt_word(np, nbit.lwe_key.data(), neg2);
-    printf("%d => negative2\n", int_negative2);
+    fprintf(log, "%d => negative2\n", int_negative2);
     const int32_t int_negative = int_negative1 + int_negative2;  // :804
 
-    FileCloser ans{fopen(path("answer.data").c_str(), "wb")};  // :809
-    if (!ans.f) throw CodecError("cannot create answer.data");
+    struct { FILE* f; } ans{io.open_answer()};  // :809
+    if (!ans.f) throw CodecError("no answer sink");
     int32_t ciphernegative = 0;  // :812-821
     if (int_negative == 1) ciphernegative = 1;
     if (int_negative == 2) ciphernegative = 2;
@@ -107,7 +129,7 @@ int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* re
     for (int i = 0; i < 32; i++)  // :822-824 fresh encryption under the nbit key
         lwe_encrypt_bit(np, nbit.lwe_key.data(), (ciphernegative >> i) & 1, rng, word.data() + i * S);
     write_lwe_samples(ans.f, n, 32, word.data(), S);
-    printf("%d => total negatives\n", ciphernegative);
+    fprintf(log, "%d => total negatives\n", ciphernegative);
 
     int32_t int_bit = 0;  // :829-856
     if (int_op == 4) {
@@ -115,16 +137,16 @@ int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* re
         for (int i = 0; i < 32; i++)
             lwe_encrypt_bit(np, nbit.lwe_key.data(), (int_bit >> i) & 1, rng, word.data() + i * S);
         write_lwe_samples(ans.f, n, 32, word.data(), S);
-        printf("%d written to answer.data\n", int_bit);
+        fprintf(log, "%d written to answer.data\n", int_bit);
         int_bit = int_bit1 >= int_bit2 ? int_bit1 : int_bit2;
     } else if (int_bit1 >= int_bit2) {
         int_bit = int_bit1;
         write_lwe_samples(ans.f, n, 32, bit1, S);
-        printf("%d written to answer.data\n", int_bit);
+        fprintf(log, "%d written to answer.data\n", int_bit);
     } else {
         int_bit = int_bit2;
         write_lwe_samples(ans.f, n, 32, bit2, S);
-        printf("%d written to answer.data\n", int_bit);
+        fprintf(log, "%d written to answer.data\n", int_bit);
     }
     if (report) {
         report->op = int_op;
@@ -135,7 +157,7 @@ int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* re
         report->gpu_ms = 0;
     }
     if (int_op == 4 && int_bit >= 256) {  // :860-864
-        printf("Cannot multiply 256 bit number!\n");
+        fprintf(log, "Cannot multiply 256 bit number!\n");
         return 126;
     }
 
@@ -158,7 +180,7 @@ int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* re
         label = "Multiplication";
     }
     if (kind == 0) return 0;  // unknown operator: main() falls through, answer.data keeps 64 samples
-    printf("%d bit %s computation\n", int_bit, label);
+    fprintf(log, "%d bit %s computation\n", int_bit, label);
     const bool size_ok = kind == CIRC_MUL ? (int_bit == 32 || int_bit == 64 || int_bit == 128)
                                           : (int_bit == 32 || int_bit == 64 || int_bit == 128 || int_bit == 256);
     if (!size_ok) return 0;  // no branch of main() matches: 64-sample answer.data = failure marker
@@ -178,25 +200,22 @@ int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* re
     memcpy(in.data() + (size_t)2 * W * WORD, carry1, WORD * 4);
     std::vector<Torus32> out(circ.outputs.size() * S);
 
-    if (!eval) {
-        owned.reset(new Evaluator(p, device));
-        owned->load_keys_host(ck.bk.data(), ck.ksk.data());
-        eval = owned.get();
-    }
-    printf("Doing the homomorphic computation...\n");
+    Evaluator* eval = get_eval();
+    if (!eval) throw std::runtime_error("no evaluator");
+    fprintf(log, "Doing the homomorphic computation...\n");
     const double t0 = now_s();
     EvalStats st;
     eval_circuit_host(*eval, circ, 1, in.data(), out.data(), &st);
     const double get_time = now_s() - t0;
-    printf("Computation Time: %lf[sec]\n", get_time);
+    fprintf(log, "Computation Time: %lf[sec]\n", get_time);
     if (kind == CIRC_MUL) {  // cloud.c:2467-2471
-        FILE* t_file = fopen(path("averagestandard.txt").c_str(), "a");
+        FILE* t_file = io.stats_path.empty() ? nullptr : fopen(io.stats_path.c_str(), "a");
         if (t_file) {
             fprintf(t_file, "%lf\n", get_time);
             fclose(t_file);
         }
     }
-    printf("writing the answer to file...\n");
+    fprintf(log, "writing the answer to file...\n");
     // result words LSW first, then ciphertextcarry1 as filler up to 9 words (e.g. :899-917)
     const size_t n_out_words = circ.outputs.size() / 32;
     write_lwe_samples(ans.f, n, circ.outputs.size(), out.data(), S);

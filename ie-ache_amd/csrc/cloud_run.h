@@ -1,10 +1,13 @@
 // `./cloud` process contract of the reference as a function (cloud_run.cpp).
 #pragma once
+#include <cstdio>
+#include <functional>
 #include <memory>
 #include <string>
 
 #include "circuit.h"
 #include "evaluator.h"
+#include "params.h"
 
 namespace ieache {
 
@@ -22,7 +25,22 @@ struct CloudRunReport {
 // `shared_eval` (optional) supplies an evaluator whose keys are already
 // resident, so cloud.key is not re-read (the reference reloads it per call,
 // cloud.c:656-658).  Throws CodecError / std::runtime_error on I/O or GPU failure.
-int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* report, int device = 0);
+int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* report, int device = 0,
+              FILE* log = nullptr /* stdout */);
+
+// The same contract on open streams instead of files in a directory: what the resident-key daemon
+// (daemon.cpp) runs when cloud.data arrives over a socket.
+struct CloudRunIO {
+    Params params;                       // of the cloud key
+    const SecretKeyData* nbit = nullptr; // the metadata key (cloud.c:661-663)
+    FILE* cloud_data = nullptr;          // 704 LweSamples (cloud.c:703-766)
+    int32_t op = 0;                      // content of operator.txt (cloud.c:769-773)
+    std::function<FILE*()> open_answer;  // called once the inputs are read (cloud.c:809)
+    std::string stats_path;              // averagestandard.txt; empty = do not append
+    FILE* log = nullptr;                 // stdout chatter; null = stdout
+};
+// get_eval is called only if a circuit is actually evaluated.
+int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_eval, CloudRunReport* report);
 
 // Host-buffer convenience: rows of (n+1) int32 in and out.
 void eval_circuit_host(Evaluator& eval, const Circuit& c, size_t batch, const Torus32* in, Torus32* out,

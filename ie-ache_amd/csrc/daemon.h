@@ -1,0 +1,54 @@
+// Resident-key Cloud daemon: the reference reloads and re-transforms ~100 MB of
+// keys on every `./cloud` launch (Cloud/cloud.c:656-663, once per operator of every expression).
+// Here one process keeps the cloud key on the GPU and serves the same contract over a local
+// (AF_UNIX) stream socket: either "run the files in this directory" or "here is cloud.data and
+// the operator, send answer.data back".  One request at a time, like the reference.
+//
+// Wire format (little-endian, no padding):
+//   request : u32 magic 'IEAC' | u32 version (1) | u32 op | u32 flags (0) | u64 payload_len | payload
+//   response: u32 magic 'IEAC' | i32 rc | u64 log_len | u64 data_len | log bytes | data bytes
+//   op PING     : no payload
+//   op RUN_DIR  : payload = directory path; the daemon reads nbit.key, cloud.data, operator.txt there
+//                 and writes answer.data (+ averagestandard.txt), exactly like `./cloud`; if that
+//                 directory's cloud.key is not the resident one, it is loaded first
+//   op RUN_DATA : payload = i32 operator | cloud.data bytes; response data = answer.data bytes
+//                 (metadata key = the daemon's nbit key)
+//   op SHUTDOWN : no payload; the daemon answers and exits its loop
+//   rc: 0 or 126 as main() of cloud.c, negative IEACHE_E* on failure (message in log)
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace ieache {
+
+constexpr uint32_t kDaemonMagic = 0x43414549u;  // "IEAC"
+constexpr uint32_t kDaemonVersion = 1;
+enum DaemonOp : uint32_t { DAEMON_PING = 1, DAEMON_RUN_DIR = 2, DAEMON_RUN_DATA = 3, DAEMON_SHUTDOWN = 4 };
+constexpr uint64_t kDaemonMaxPayload = 64ull << 20;  // cloud.data is 1.8 MB at n=630
+
+struct DaemonConfig {
+    std::string socket_path;
+    std::string cloud_key_path;  // loaded before the first accept
+    std::string nbit_key_path;   // for RUN_DATA; empty = nbit.key next to cloud.key
+    int device = 0;
+    int64_t max_requests = -1;   // < 0: until SHUTDOWN
+    bool announce = true;        // print "cloudd: ready on <path>" once listening
+};
+
+// Blocks serving requests; returns the number served.  Throws on setup failure
+// (key load, GPU, bind).  A failing request is answered with a negative rc and
+// the daemon keeps running.
+int64_t daemon_serve(const DaemonConfig& cfg);
+
+struct DaemonReply {
+    int32_t rc = 0;
+    std::string log;
+    std::vector<unsigned char> data;
+};
+// Client side.  Throws std::runtime_error when the daemon cannot be reached or
+// answers garbage.
+DaemonReply daemon_request(const std::string& socket_path, uint32_t op, const void* payload, size_t len);
+
+}  // namespace ieache

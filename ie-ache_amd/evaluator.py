@@ -133,6 +133,12 @@ def lib():
     L.ieache_write_samples.argtypes = [C.c_char_p, C.c_int32, C.c_size_t, i32p, C.c_int]
     L.ieache_alice.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, u32p, C.c_uint64]
     L.ieache_verif.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, u32p, u32p, u32p]
+    L.ieache_serve.restype = C.c_int64
+    L.ieache_serve.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int64]
+    L.ieache_client_ping.argtypes = [C.c_char_p]
+    L.ieache_client_run_dir.argtypes = [C.c_char_p, C.c_char_p]
+    L.ieache_client_run_data.argtypes = [C.c_char_p, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ieache_client_shutdown.argtypes = [C.c_char_p]
     _LIB = L
     return L
 

@@ -186,6 +186,31 @@ int ieache_alice(const char* secret_key_path, const char* nbit_key_path, const c
 int ieache_verif(const char* secret_key_path, const char* nbit_key_path, const char* answer_data_path,
                  uint32_t* sign_code, uint32_t* bit_size, uint32_t* words9);
 
+/* ------------------------------------------------------------------ *
+ * 5. Resident-key daemon.  The reference reloads and     *
+ *    re-transforms the cloud key in every ./cloud launch               *
+ *    (cloud.c:656-663), i.e. once per operator; its caller             *
+ *    (dragonfly_cipher_cloud.py:1233) only needs "run the files in     *
+ *    this directory".  ieache_serve keeps the key on the GPU and       *
+ *    serves that request over an AF_UNIX stream socket (wire format:   *
+ *    csrc/daemon.h); the `cloud` shim forwards to it when              *
+ *    IEACHE_DAEMON=<socket path> is set.                               *
+ * ------------------------------------------------------------------ */
+/* Blocks.  nbit_key_path may be NULL (= nbit.key next to cloud.key; only
+ * RUN_DATA needs it).  max_requests < 0: until a shutdown request or
+ * SIGINT/SIGTERM.  Returns the number of requests served or IEACHE_E*. */
+int64_t ieache_serve(const char* socket_path, const char* cloud_key_path, const char* nbit_key_path, int device,
+                     int64_t max_requests);
+/* clients: return what main() of cloud.c would (0 / 126) or IEACHE_E*;
+ * IEACHE_ENODEV when no daemon listens on socket_path */
+int ieache_client_ping(const char* socket_path);
+int ieache_client_run_dir(const char* socket_path, const char* workdir);
+/* cloud.data bytes + operator code in, answer.data bytes out (caller buffer;
+ * *answer_len = bytes needed even when answer_cap is too small -> IEACHE_EINVAL) */
+int ieache_client_run_data(const char* socket_path, int operator_code, const void* cloud_data, size_t cloud_data_len,
+                           void* answer, size_t answer_cap, size_t* answer_len);
+int ieache_client_shutdown(const char* socket_path);
+
 #ifdef __cplusplus
 }
 #endif

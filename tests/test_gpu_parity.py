@@ -451,3 +451,83 @@ def test_old_libtfhe_parameter_set_on_fast_kernel(ia, gpu_ctx):
     ctx.force_generic(True)
     assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), out)
     ctx.force_generic(False)
+
+
+def test_resident_key_daemon(ia, O, tmp_path):
+    """`cloudd` keeps the cloud key on the GPU and serves the ./cloud contract over a
+    local socket; results equal the in-process run and the oracle, bit for bit."""
+    import ctypes as C
+    import signal
+    import subprocess
+    from ieache_amd import daemon, tools
+    p = ia.default_params().copy(n=6, N=64)
+    S = 4 * p.n + 16
+    tools.keygen_files(tmp_path, p)
+    sock = tmp_path / "cloudd.sock"
+    proc = daemon.spawn(sock, tmp_path / "cloud.key")
+    try:
+        assert daemon.ping(sock)[0] == 0
+        # RUN_DIR through compute(): 2^30 + 2^30, then the oracle on the same cloud.data
+        rc, size, ok = _run_file_contract_daemon(ia, tmp_path, sock, 1, 32, 1 << 30, 0, 1 << 30, 0)
+        assert (rc, size, ok) == (0, 352 * S, True)
+        assert tools.verif_interpret(1, *tools.verif(tmp_path)) == 1 << 31
+        _, bk, ksk = tools.read_cloud_key(tmp_path / "cloud.key")
+        ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, bk, ksk)
+        data = tools.read_samples(tmp_path / "cloud.data", p.n).reshape(22, 32, p.n + 1)
+        rc2, ref = ck.cloud_values(1, 0, 32, data[2:10], data[13:21], data[10])
+        ans = tools.read_samples(tmp_path / "answer.data", p.n).reshape(11, 32, p.n + 1)
+        assert rc2 == 0 and np.array_equal(ans[2:], ref)
+        # RUN_DATA: the same bytes over the socket give the same value samples back
+        raw = (tmp_path / "cloud.data").read_bytes()
+        rc, log, answer = daemon.run_data(sock, 1, raw)
+        assert rc == 0 and len(answer) == 352 * S and "Computation Time" in log
+        (tmp_path / "answer_sock.data").write_bytes(answer)
+        ans2 = tools.read_samples(tmp_path / "answer_sock.data", p.n).reshape(11, 32, p.n + 1)
+        assert np.array_equal(ans2[2:], ref)
+        # MUL appends averagestandard.txt (cloud.c:2467-2471); 256-bit MUL is refused with 126 and 64 samples
+        rc, size, ok = _run_file_contract_daemon(ia, tmp_path, sock, 3, 32, 12345, 0, 678, 2)
+        assert rc == 0 and ok and (tmp_path / "averagestandard.txt").exists()
+        code, bit_size, words = tools.verif(tmp_path)
+        assert (code, bit_size, words[0] | words[1] << 32) == (2, 64, 12345 * 678)
+        rc, size, ok = _run_file_contract_daemon(ia, tmp_path, sock, 3, 256, 5, 0, 5, 0)
+        assert (rc, size, ok) == (126, 64 * S, False)
+        # the `cloud` shim hands over to the daemon when IEACHE_DAEMON is set
+        tools.alice(tmp_path, 0, 32, 1000, seed=41)
+        tools.alice(tmp_path, 0, 32, 234, seed=42, append=True)
+        (tmp_path / "operator.txt").write_text("2")
+        exe = os.path.join(os.path.dirname(ia.library_path()), "cloud")
+        r = subprocess.run([exe], cwd=tmp_path, env=dict(os.environ, IEACHE_DAEMON=str(sock)), capture_output=True, timeout=120)
+        assert r.returncode == 0 and b"Computation Time" in r.stdout and b"daemon" not in r.stderr
+        assert tools.verif_interpret(2, *tools.verif(tmp_path)) == 766
+        # failures are answered, not fatal: missing directory, truncated cloud.data, unknown request
+        rc, log = daemon.run_dir(sock, tmp_path / "no_such_dir")
+        assert rc == -5 and "nbit.key" in log
+        rc, log, answer = daemon.run_data(sock, 1, raw[:1000])
+        assert rc == -5 and answer == b""
+        assert daemon.request(sock, 99)[0] == -22
+        assert daemon.ping(sock)[0] == 0
+        # a directory holding a different cloud.key (a new session): the daemon switches keys
+        other = tmp_path / "session2"
+        other.mkdir()
+        seed = (C.c_uint32 * 3)(7, 8, 9)
+        assert ia.lib().ieache_keygen_files(os.fsencode(other), C.byref(p), seed, 3, None, 0) == 0
+        tools.alice(other, 0, 32, 40, seed=51)
+        tools.alice(other, 0, 32, 2, seed=52, append=True)
+        rc, size, ok = ia.compute(1, other, daemon_socket=sock, failure_size=64 * S)
+        assert rc == 0 and ok and tools.verif_interpret(1, *tools.verif(other)) == 42
+        assert daemon.shutdown(sock) == 0
+        assert proc.wait(timeout=60) == 0 and not sock.exists()
+    finally:
+        if proc.poll() is None:
+            proc.send_signal(signal.SIGTERM)
+            try:
+                proc.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+
+
+def _run_file_contract_daemon(ia, tmp_path, sock, operator, bits, a, sa, b, sb):
+    from ieache_amd import tools
+    tools.alice(tmp_path, sa, bits, a, seed=31)
+    tools.alice(tmp_path, sb, bits, b, seed=32, append=True)
+    return ia.compute(operator, tmp_path, daemon_socket=sock, failure_size=64 * (4 * 6 + 16))
