@@ -26,3 +26,15 @@ tools.alice(d, 0, 32, 5, seed=3); tools.alice(d, 0, 32, 7, seed=4, append=True)
 open(os.path.join(d, "operator.txt"), "w").write("1")
 t = time.perf_counter(); rc = subprocess.call([os.path.join(os.path.dirname(ia.library_path()), "cloud")], cwd=d, stdout=subprocess.DEVNULL)
 print("cold ./cloud 32-bit A+B (incl. 114 MB key load): %.3f s rc=%d" % (time.perf_counter() - t, rc))
+# the same executable handing over to a resident-key daemon (IEACHE_DAEMON): no key load per operator
+from ieache_amd import daemon
+del ctx
+sock = os.path.join(d, "cloudd.sock")
+t = time.perf_counter(); proc = daemon.spawn(sock, os.path.join(d, "cloud.key")); print("cloudd start (key load + transform) %.2f s" % (time.perf_counter() - t))
+for rep in range(2):
+    t = time.perf_counter(); rc = subprocess.call([os.path.join(os.path.dirname(ia.library_path()), "cloud")], cwd=d, stdout=subprocess.DEVNULL, env=dict(os.environ, IEACHE_DAEMON=sock))
+    print("./cloud via cloudd 32-bit A+B: %.3f s rc=%d" % (time.perf_counter() - t, rc))
+assert tools.verif_interpret(1, *tools.verif(d)) == 12
+raw = open(os.path.join(d, "cloud.data"), "rb").read()
+t = time.perf_counter(); rc, log, ans = daemon.run_data(sock, 1, raw); print("RUN_DATA over the socket 32-bit A+B: %.3f s rc=%d (%d B in, %d B out)" % (time.perf_counter() - t, rc, len(raw), len(ans)))
+daemon.shutdown(sock); proc.wait(timeout=60)
