@@ -10,6 +10,7 @@ bool supported(const Params& p);
 // number of double2 elements of the BK spectrum in this kernel's layout
 size_t spectrum_elems(const Params& p);
 size_t lds_bytes(const Params& p);
+int32_t bara_stride(const Params& p);
 // raw BK [n][2l][2][N] int32 (device) -> two-limb spectrum [n][2l][4][8][64] double2
 void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, hipStream_t stream);
 // bytes of blind-rotation state (accumulator + rotation amounts) one gate instance keeps in HBM between slices
@@ -24,6 +25,9 @@ int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const d
 // s_memtime diagnostics printed to stderr; 2 = LDS transposes with workgroup barriers; 3 = cross-lane
 // (DPP / v_permlane*_swap) transposes; 4 = 3 with diagnostics.  All produce identical bits.
 int32_t default_variant();
+// 7 = 2L waves per gate (k_blind_rotate_wide): lower latency per gate, for launches of few gates;
+// takes any slice length up to n (one launch for the whole rotation)
+constexpr int32_t kVariantWide = 7;
 
 }  // namespace w64
 }  // namespace ieache

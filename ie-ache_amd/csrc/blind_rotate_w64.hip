@@ -604,6 +604,177 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 }
 
 
+// ---- K3 (+K4), latency-oriented: 2L waves per gate instance ----
+// For narrow levels (a single expression, the reference's own mode) the time of a level is the
+// LATENCY of one blind rotation, and two waves walking 3 forward + 2 inverse transforms one after
+// the other leave most of the CU idle.  Here one workgroup of 2L waves takes one gate: wave w
+// (w = p*L + q) decomposes digit q of polynomial p and transforms it -- all 2L forward transforms
+// at once -- and publishes the spectrum in its own tile; waves 0..3 then each own ONE spectrum
+// accumulator (output polynomial w>>1, limb w&1), MAC all 2L rows into it, inverse-transform it and
+// add their share to the accumulator polynomial in LDS with ds_add_u32 (addition mod 2^32
+// commutes, so the two limb waves need no ordering).  Three barriers per step.
+// Same arithmetic as k_blind_rotate_w2 up to the order of exact-after-rounding FP64 sums, so the
+// integers it produces are identical.
+// dynamic LDS: sT [2L][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32 | bara [i1-i0] u16
+template <int L, int BGBIT, bool DIAG>
+__global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const double2* __restrict__ bkf,
+                                                             const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                             int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
+                                                             unsigned long long* diag) {
+    constexpr int NW = 2 * L, NT = 64 * NW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* sT_all = reinterpret_cast<double2*>(smem);
+    double2* sTw = sT_all + NW * kTile;
+    int32_t* acc = reinterpret_cast<int32_t*>(sTw + kTwElems);
+    uint16_t* s_bara = reinterpret_cast<uint16_t*>(acc + 2 * kN);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;
+    const int64_t item = (int64_t)blockIdx.x;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    build_twiddles(sTw, tid, NT);
+    const LaneRoots R = make_roots(sTw, lane);
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+        for (int idx = tid; idx < 2 * kN / 4; idx += NT) dst[idx] = src[idx];
+        const uint16_t* bara = st_bara + (size_t)item * nb;
+        for (int idx = tid; idx < i1 - i0; idx += NT) s_bara[idx] = bara[i0 + idx];
+    }
+    __syncthreads();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1), maskBg = (1u << BGBIT) - 1;
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;
+    const int pw = wave / L, qw = wave - pw * L;  // forward role: digit qw of polynomial pw
+    const int sh = 32 - (qw + 1) * BGBIT;
+    const int32_t* accp = acc + pw * kN;
+    const bool is_out = wave < 4;                 // inverse role: output polynomial wave>>1, limb wave&1
+    uint32_t* acco = reinterpret_cast<uint32_t*>(acc) + (wave >> 1) * kN;
+    const int lsh = (wave & 1) * 16;
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    if (DIAG) tlast = stamp();
+#define IEACHE_STAMP(idx)                      \
+    if (DIAG) {                                \
+        const unsigned long long t_ = stamp(); \
+        tsum[idx] += t_ - tlast;               \
+        tlast = t_;                            \
+    }
+
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readfirstlane((int32_t)s_bara[i - i0]);
+        if (a == 0) continue;  // workgroup-uniform
+        // BK_i rows [2L][4][8][64]: this wave (as an output owner) reads block `wave` of every row.
+        // One CU takes 64 B/clk from its vector-memory path, i.e. >= 3 000 cycles for the 192 KiB of a
+        // step, so the loads are issued in three instalments spread over the step: rows 0,1 now (they
+        // fly under the decomposition and the transform), rows 2,3 after the transform, rows 4,5 once
+        // rows 0,1 are consumed.
+        const double2* __restrict__ bki = bkf + (size_t)i * (2 * L * 4 * kM) + (size_t)wave * kM + lane;
+        double2 bA[2][8], bB[2][8], s[8];
+        if (is_out) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                bA[0][k] = bki[(size_t)0 * 4 * kM + k * 64];
+                bA[1][k] = bki[(size_t)1 * 4 * kM + k * 64];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int32_t lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // opaque: keeps 16 per-coefficient LDS addresses from being hoisted (and spilled)
+        double2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int32_t j = 64 * r + lane_o;
+            const uint32_t u0 = (uint32_t)rot_coef(accp, j, a, kN) - (uint32_t)accp[j] + dec_offset;
+            const uint32_t u1 = (uint32_t)rot_coef(accp, j + kM, a, kN) - (uint32_t)accp[j + kM] + dec_offset;
+            const int32_t e0 = (int32_t)((u0 >> sh) & maskBg) - (int32_t)halfBg;
+            const int32_t e1 = (int32_t)((u1 >> sh) & maskBg) - (int32_t)halfBg;
+            x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                          : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+        }
+        IEACHE_STAMP(0)
+        fft512_forward<true>(x, sT, lane, R);
+        IEACHE_STAMP(1)
+#pragma unroll
+        for (int k = 0; k < 8; k++) sT[k * 64 + lane] = x[k];  // publish
+        __builtin_amdgcn_sched_barrier(0);
+        if (is_out) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                bB[0][k] = bki[(size_t)2 * 4 * kM + k * 64];
+                bB[1][k] = bki[(size_t)3 * 4 * kM + k * 64];
+            }
+        }
+        IEACHE_STAMP(2)
+        __syncthreads();  // A: all 2L spectra are in their tiles
+        IEACHE_STAMP(3)
+        if (is_out) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = make_double2(0.0, 0.0);
+#define IEACHE_MAC_ROW(row, B)                                                                          \
+    {                                                                                                   \
+        const double2* sp = sT_all + (row) * kTile + lane;                                              \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                 \
+            const double2 y = sp[k * 64];                                                               \
+            s[k] = make_double2(fma(y.x, B[k].x, fma(-y.y, B[k].y, s[k].x)), fma(y.x, B[k].y, fma(y.y, B[k].x, s[k].y))); \
+        }                                                                                               \
+    }
+            IEACHE_MAC_ROW(0, bA[0])
+            IEACHE_MAC_ROW(1, bA[1])
+            if (NW > 4) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    bA[0][k] = bki[(size_t)4 * 4 * kM + k * 64];
+                    bA[1][k] = bki[(size_t)5 * 4 * kM + k * 64];
+                }
+            }
+            IEACHE_MAC_ROW(2, bB[0])
+            IEACHE_MAC_ROW(3, bB[1])
+            if (NW > 4) {
+                IEACHE_MAC_ROW(4, bA[0])
+                IEACHE_MAC_ROW(5, bA[1])
+            }
+#undef IEACHE_MAC_ROW
+        }
+        IEACHE_STAMP(4)
+        __syncthreads();  // B: every spectrum has been consumed, tiles are scratch again
+        IEACHE_STAMP(5)
+        if (is_out) {
+            fft512_inverse<true>(s, sT, lane, R);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
+                const uint32_t c0 = (uint32_t)__double2loint(z.x + kMagic) << lsh;
+                const uint32_t c1 = (uint32_t)__double2loint(z.y + kMagic) << lsh;
+                const int32_t j = 64 * r + lane;
+                atomicAdd(&acco[j], c0);       // ds_add_u32; the partner limb adds its share to the same word
+                atomicAdd(&acco[j + kM], c1);
+            }
+        }
+        IEACHE_STAMP(6)
+        __syncthreads();  // C: accumulator complete before the next decomposition
+        IEACHE_STAMP(7)
+    }
+#undef IEACHE_STAMP
+    if (DIAG && diag && lane == 0 && (wave == 0 || wave == 4)) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) atomicAdd(&diag[(wave >> 2) * 8 + t], tsum[t]);
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = tid; j <= kN; j += NT)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+        for (int idx = tid; idx < 2 * kN / 4; idx += NT) dst[idx] = src[idx];
+    }
+}
+
+
 }  // namespace
 
 // N=1024, k=1 with either libtfhe parameter set: l=3/Bgbit=7 (>= v1.1, "128-bit") or l=2/Bgbit=10
@@ -621,6 +792,10 @@ size_t lds_bytes(const Params& p) {
 
 int32_t bara_stride(const Params& p) { return (p.n + 7) & ~7; }
 
+size_t lds_bytes_wide(const Params& p) {
+    return (size_t)(2 * p.l * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)bara_stride(p) * 2;
+}
+
 size_t state_bytes_per_item(const Params& p) { return (size_t)bara_stride(p) * 2 + (size_t)2 * kN * 4; }
 
 void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, hipStream_t stream) {
@@ -637,13 +812,16 @@ static unsigned long long* diag_buf() {
     }
     return p;
 }
-static void diag_report(hipStream_t stream, int64_t items, int32_t nsteps) {
+static void diag_report(hipStream_t stream, int64_t items, int32_t nsteps, int variant) {
     unsigned long long h[16];
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h, diag_buf(), sizeof h, hipMemcpyDeviceToHost);
     (void)hipMemset(diag_buf(), 0, sizeof h);
-    static const char* names[8] = {"decompose", "build+fwdFFT(x3)", "tile+ownBK+MAC(x3)", "barrier1(x3)", "partner+BK+MAC(x3)",
-                                   "barrier2(x3)", "invFFT x2+update", "end barrier"};
+    static const char* names_w2[8] = {"decompose", "build+fwdFFT(x3)", "tile+ownBK+MAC(x3)", "barrier1(x3)", "partner+BK+MAC(x3)",
+                                      "barrier2(x3)", "invFFT x2+update", "end barrier"};
+    static const char* names_wide[8] = {"head+decompose", "fwdFFT", "publish+BK issue", "barrier A", "MAC rows",
+                                        "barrier B", "invFFT+update", "barrier C"};  // "wave 1" = wave 4 (no output role)
+    const char* const* names = variant >= kVariantWide ? names_wide : names_w2;
     const double denom = (double)items * (nsteps > 0 ? nsteps : 1);
     for (int w = 0; w < 2; w++) {
         double tot = 0;
@@ -658,6 +836,21 @@ template <int L, int BGBIT>
 static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream_t stream, const DevKeys& K, const double2* d_bkf,
                          const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e) {
     unsigned long long* const nodiag = nullptr;
+    if (variant == kVariantWide || variant == kVariantWide + 1) {
+        static const bool attr_set = [] {  // > 64 KiB of dynamic LDS has to be allowed explicitly
+            return hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024) == hipSuccess;
+        }();
+        (void)attr_set;
+        const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
+        if (variant == kVariantWide)
+            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag);
+        else
+            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, true>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf());
+        return;
+    }
     switch (variant) {
         case 1: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
         case 2: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
@@ -690,7 +883,9 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
     uint16_t* st_bara = reinterpret_cast<uint16_t*>(st_acc + (size_t)items * 2 * kN);
     hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
-    const int32_t S = (slice >= 1 && slice <= 64) ? slice : default_slice();
+    // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
+    const int32_t max_slice = variant >= kVariantWide ? nb : 64;
+    const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
         Torus32* e = (i1 == nsteps) ? ext : nullptr;  // the last slice extracts instead of storing the accumulator
@@ -700,7 +895,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
         else
             launch_slice<2, 10>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e);
     }
-    if (variant == 1 || variant == 4) diag_report(stream, items, nsteps);
+    if (variant == 1 || variant == 4 || variant == kVariantWide + 1) diag_report(stream, items, nsteps, variant);
     if (nsteps == 0 && ext) {
         // degenerate (steps == 0): extraction straight from the initial accumulator
         if (p.l == 3)

@@ -66,7 +66,9 @@ public:
     // Maximum gate instances per launch (bounds the scratch buffers).
     void set_chunk(size_t items);
     // Named tuning knobs: "chunk", "force_generic", "ks_batch_min" (gate instances from which the
-    // gate-batched key switch is used), "br_slice" (CMux steps per blind-rotation launch, 1..64).
+    // gate-batched key switch is used), "br_slice" (CMux steps per blind-rotation launch, 1..64),
+    // "br_wide_max" (launches of at most this many gate instances use the latency-oriented
+    // 2L-waves-per-gate kernel; default = the device's CU count, 0 = never), "br_variant".
     // Returns false for an unknown name or a value out of range.
     bool set_option(const std::string& name, int64_t value);
     std::string kernel_variant() const;

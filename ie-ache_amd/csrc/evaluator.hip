@@ -493,6 +493,9 @@ struct Evaluator::Impl {
     int64_t ks_batch_min = 4096;  // use it from this many gate instances per launch (one workgroup walk takes ~5 ms)
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
     int32_t br_variant = w64::default_variant();
+    // launches of at most this many gate instances (one per CU) use the 2L-waves-per-gate kernel in a
+    // single launch: what matters there is the latency of one blind rotation, not throughput
+    int64_t br_wide_max = 0;
 };
 
 Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(new Impl) {
@@ -502,6 +505,12 @@ Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(n
     if (device < 0 || device >= count) throw std::runtime_error("no such HIP device");
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    {
+        int cus = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        d_->br_wide_max = cus;  // one workgroup of the wide kernel fills a CU
+        if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
+    }
     DevKeys& K = d_->K;
     K.n = p.n;
     K.N = p.N;
@@ -583,9 +592,11 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         force_generic_ = value != 0;
     } else if (name == "ks_batch_min" && value >= 0) {
         d_->ks_batch_min = value;
-    } else if (name == "br_slice" && value >= 1 && value <= 64) {
+    } else if (name == "br_wide_max" && value >= 0) {
+        d_->br_wide_max = value;
+    } else if (name == "br_slice" && value >= 1 && value <= 4096) {
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 6) {
+    } else if (name == "br_variant" && value >= 0 && value <= 8) {
         d_->br_variant = (int32_t)value;
     } else {
         return false;
@@ -678,6 +689,9 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
             HIP_CHECK(hipMalloc(&d->br_state, items * w64::state_bytes_per_item(p)));
             d->br_state_items = items;
         }
+        if (d->br_variant == 0 && cnt <= d->br_wide_max)
+            return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, w64::bara_stride(p), w64::kVariantWide,
+                               stream);
         return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, d->br_slice, d->br_variant, stream);
     }
     else

@@ -7,6 +7,9 @@ from ieache_amd import tools
 p = ia.default_params()
 k = tools.keygen_raw(p, (1, 2, 3))
 ctx = ia.Context.from_arrays(p, k["bk"], k["ksk"])
+for opt in ("br_variant", "br_slice", "ks_batch_min"):  # e.g. BR_VARIANT=7 BR_SLICE=630
+    if os.environ.get(opt.upper()):
+        ctx.set_option(opt, int(os.environ[opt.upper()]))
 rng = np.random.default_rng(0)
 counts = [int(c) for c in (sys.argv[1:] or ["1024", "4096", "8192"])]
 mx = max(counts)
@@ -21,6 +24,6 @@ for count in counts:
         if best is None or st.blind_rotate_ms < best.blind_rotate_ms:
             best = st
     ok = np.array_equal(tools.decrypt_bits(p, k["lwe_key"], out), bits[0][:count] & bits[1][:count])
-    print("variant", os.environ.get("IEACHE_BR_VARIANT", "0"), ctx.kernel_variant, "count", count, "ok", ok,
+    print("variant", os.environ.get("BR_VARIANT", os.environ.get("IEACHE_BR_VARIANT", "0")), "slice", os.environ.get("BR_SLICE", "16"), ctx.kernel_variant, "count", count, "ok", ok,
           "BR ms %.2f (%.0f gates/s)  KS ms %.2f (%.0f gates/s)" % (best.blind_rotate_ms, count / best.blind_rotate_ms * 1e3,
           best.keyswitch_ms, count / best.keyswitch_ms * 1e3), flush=True)

@@ -306,8 +306,8 @@ def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
 
 
 def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
-    """Fast (two-waves-per-gate, sliced) and generic kernels, every slice size, both key-switch
-    kernels: all must produce identical bits (and the oracle's)."""
+    """Fast (two-waves-per-gate, sliced), latency (2L-waves-per-gate) and generic kernels, every slice
+    size, both key-switch kernels: all must produce identical bits (and the oracle's)."""
     kb, ctx = gpu_ctx(16, 1024)
     assert "radix8" in ctx.kernel_variant
     rng = np.random.default_rng(3)
@@ -324,7 +324,19 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     for variant in (2, 3):                                 # workgroup-barrier sync; cross-lane (DPP/permlane) transposes
         ctx.set_option("br_variant", variant)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:300], b[:300]), ref[:300]), variant
+    ctx.set_option("br_variant", 7)                        # 2L-waves-per-gate (latency) kernel, forced for every launch size
+    for sl in (16, 5, 4096):                               # sliced, ragged, whole rotation in one launch
+        ctx.set_option("br_slice", sl)
+        assert np.array_equal(ctx.gates(ia.GATE_AND, a[:600], b[:600]), ref[:600]), sl
+    ctx.set_option("br_slice", 16)
     ctx.set_option("br_variant", 0)
+    # policy: launches of <= br_wide_max gates take the wide kernel by themselves (default = CU count)
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a[:200], b[:200]), ref[:200])
+    ctx.set_option("br_wide_max", 0)
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a[:200], b[:200]), ref[:200])
+    ctx.set_option("br_wide_max", 1 << 20)
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
+    ctx.set_option("br_wide_max", 256)
     ctx.set_option("ks_batch_min", 1 << 40)                # per-gate vectorised key switch
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
     ctx.set_option("ks_batch_min", 1)                      # gate-batched key switch even for tiny launches
@@ -335,7 +347,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
     ctx.force_generic(False)
     with pytest.raises(ia.IeacheError):
-        ctx.set_option("br_slice", 65)
+        ctx.set_option("br_slice", 4097)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("no_such_knob", 1)
 
@@ -440,6 +452,9 @@ def test_old_libtfhe_parameter_set_on_fast_kernel(ia, gpu_ctx):
     assert np.array_equal(kb.dec(out), a_bits ^ b_bits)
     for i in range(16):
         assert np.array_equal(kb.ck.gate("xor", a[i], b[i]), out[i]), i
+    ctx.set_option("br_wide_max", 0)  # 16 gates took the 2L = 4 waves-per-gate kernel; now the two-wave one
+    assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), out)
+    ctx.set_option("br_wide_max", 256)
     x = kb.enc([1, 0, 1], 63)
     acc = ctx.debug_blind_rotate(x, 3)
     for i in range(3):
