@@ -684,12 +684,26 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
         __builtin_amdgcn_sched_barrier(0);
         int32_t lane_o = lane;
         asm volatile("" : "+v"(lane_o));  // opaque: keeps 16 per-coefficient LDS addresses from being hoisted (and spilled)
-        double2 x[8];
+        // all 32 LDS reads first, then the arithmetic: left to itself the compiler waits for every read
+        // before issuing the next one (16 exposed LDS round trips = 2 000 cycles per step)
+        uint32_t rv0[8], rv1[8], pv0[8], pv1[8];
+        const int32_t jb = (lane_o - a) & (2 * kN - 1);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int32_t j = 64 * r + lane_o;
-            const uint32_t u0 = (uint32_t)rot_coef(accp, j, a, kN) - (uint32_t)accp[j] + dec_offset;
-            const uint32_t u1 = (uint32_t)rot_coef(accp, j + kM, a, kN) - (uint32_t)accp[j + kM] + dec_offset;
+            rv0[r] = (uint32_t)accp[(jb + 64 * r) & (kN - 1)];        // X^a * acc at j      (sign applied below)
+            rv1[r] = (uint32_t)accp[(jb + 64 * r + kM) & (kN - 1)];   //            at j + 512
+            pv0[r] = (uint32_t)accp[j];
+            pv1[r] = (uint32_t)accp[j + kM];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t n0 = 0u - (((uint32_t)(jb + 64 * r) >> 10) & 1u);        // all ones where the rotation wrapped
+            const uint32_t n1 = 0u - (((uint32_t)(jb + 64 * r + kM) >> 10) & 1u);
+            const uint32_t u0 = ((rv0[r] ^ n0) - n0) - pv0[r] + dec_offset;
+            const uint32_t u1 = ((rv1[r] ^ n1) - n1) - pv1[r] + dec_offset;
             const int32_t e0 = (int32_t)((u0 >> sh) & maskBg) - (int32_t)halfBg;
             const int32_t e1 = (int32_t)((u1 >> sh) & maskBg) - (int32_t)halfBg;
             x[r] = r == 0 ? make_double2((double)e0, (double)e1)
