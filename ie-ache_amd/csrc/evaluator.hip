@@ -18,6 +18,7 @@
 #include "evaluator.h"
 
 #include "blind_rotate_w64.h"
+#include "keyswitch_sliced.h"
 #include "device_common.h"
 
 #include <algorithm>
@@ -468,6 +469,7 @@ __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus3
 
 // ------------------------------------------------------------------------
 struct Evaluator::Impl {
+    Params p;
     DevKeys K{};
     double2* bkf = nullptr;
     double2* bkf_w64 = nullptr;  // spectrum in the wave-per-gate kernel's layout
@@ -491,6 +493,10 @@ struct Evaluator::Impl {
     int ks_nld = 0;  // dwordx4 loads per KSK row per wave; 0 = use the scalar kernel
     bool ks_batch_ok = false;     // gate-batched key switch usable (base == 4, digits fit 16 bits, columns fit 8 waves)
     int64_t ks_batch_min = 4096;  // use it from this many gate instances per launch (one workgroup walk takes ~5 ms)
+    bool ks_sliced_ok = false;    // hand-scheduled sliced variant of it usable (t = 8, basebit = 2)
+    int64_t ks_sliced_min = 2048; // ... and used from this many gate instances per launch
+    int32_t ks_slice = 0;         // coefficients per launch of the sliced key switch; 0 = the whole walk
+    int32_t ks_gates = 0;         // gate instances per workgroup there (8 / 16 / 32); 0 = by launch size
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
     int32_t br_variant = w64::default_variant();
     // launches of at most this many gate instances (one per CU) use the 2L-waves-per-gate kernel in a
@@ -511,6 +517,7 @@ Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(n
         d_->br_wide_max = cus;  // one workgroup of the wide kernel fills a CU
         if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
     }
+    d_->p = p;
     DevKeys& K = d_->K;
     K.n = p.n;
     K.N = p.N;
@@ -550,6 +557,8 @@ Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(n
         d_->ksv_lds = (size_t)(p.N + 4) * 4 + (size_t)p.N * p.ks_t * 4 + (size_t)8 * K.stride * 4;
         d_->ks_batch_ok = K.ks_base == 4 && p.ks_t * p.ks_basebit <= 16 && p.ks_t % 4 == 0 && nld <= 4;
         if (const char* e = getenv("IEACHE_KS_BATCH_MIN")) d_->ks_batch_min = atoll(e);
+        d_->ks_sliced_ok = kss::supported(p) && nld <= 4;
+        if (const char* e = getenv("IEACHE_KS_SLICED_MIN")) d_->ks_sliced_min = atoll(e);
         if (d_->ks_batch_ok)
             HIP_CHECK(hipFuncSetAttribute((const void*)k_keyswitch_batch<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)((size_t)16 * p.N * 2 + 64)));
@@ -592,6 +601,12 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         force_generic_ = value != 0;
     } else if (name == "ks_batch_min" && value >= 0) {
         d_->ks_batch_min = value;
+    } else if (name == "ks_sliced_min" && value >= 0) {
+        d_->ks_sliced_min = value;
+    } else if (name == "ks_slice" && value >= 0 && value <= kss::max_slice()) {
+        d_->ks_slice = (int32_t)value;
+    } else if (name == "ks_gates" && (value == 0 || value == 8 || value == 16 || value == 32)) {
+        d_->ks_gates = (int32_t)value;
     } else if (name == "br_wide_max" && value >= 0) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 1 && value <= 4096) {
@@ -632,7 +647,11 @@ void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
     const size_t npoly = (size_t)p_.n * K.kpl * 2;
     if (!d_->bkf) HIP_CHECK(hipMalloc(&d_->bkf, npoly * 2 * K.M * sizeof(double2)));
     const size_t ks_rows = (size_t)p_.k * p_.N * p_.ks_t * K.ks_base;
-    if (!d_->ksk) HIP_CHECK(hipMalloc(&d_->ksk, ks_rows * K.stride * 4));
+    if (!d_->ksk) {
+        // 8 rows of slack: the sliced key switch prefetches two positions past the end of its walk
+        HIP_CHECK(hipMalloc(&d_->ksk, (ks_rows + 8) * K.stride * 4));
+        HIP_CHECK(hipMemsetAsync(d_->ksk + ks_rows * K.stride, 0, (size_t)8 * K.stride * 4, stream_));
+    }
     K.bkf = d_->bkf;
     K.ksk = d_->ksk;
     hipLaunchKernelGGL(k_bk_to_spectrum, dim3((unsigned)npoly), dim3(kThreads), 2 * K.M * sizeof(double2), stream_, K,
@@ -705,6 +724,10 @@ static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkD
     const DevKeys& K = d->K;
     const dim3 grid((unsigned)cnt), blk(kKsThreads);
     const int nld = force_generic ? 0 : d->ks_nld;
+    if (nld > 0 && d->ks_sliced_ok && cnt >= d->ks_sliced_min) {
+        kss::launch(d->p, K, w, cnt, ext, flat_out, d->ks_slice, d->ks_gates, stream);
+        return;
+    }
     if (nld > 0 && d->ks_batch_ok && cnt >= d->ks_batch_min) {
         constexpr int G = 16;
         const size_t lds = (size_t)G * K.N * 2 + (size_t)G * 4;
