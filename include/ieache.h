@@ -117,8 +117,8 @@ int ieache_ctx_cloud_run(ieache_ctx* ctx, const char* workdir);
 /* tuning / test knobs */
 int ieache_ctx_set_chunk(ieache_ctx* ctx, int64_t gate_instances_per_launch);
 int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
-/* named knobs: "chunk", "force_generic", "ks_batch_min", "br_slice", "br_wide_max", "br_variant"
- * (see csrc/evaluator.h) */
+/* named knobs: "chunk", "force_generic", "ks_sliced_min", "ks_gates", "ks_slice", "ks_batch_min",
+ * "br_slice", "br_wide_max", "br_variant" (see csrc/evaluator.h) */
 int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value);
 const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx);
 
