@@ -3,6 +3,7 @@
 
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -120,7 +121,9 @@ void ieache_default_params(ieache_params* out) {
 }
 
 int ieache_cloud_run(const char* workdir) {
-    return guarded([&] { return cloud_run(workdir ? workdir : ".", nullptr, nullptr, 0); });
+    // the reference binary takes no arguments, so the GPU is chosen through the environment
+    const char* dev = getenv("IEACHE_DEVICE");
+    return guarded([&] { return cloud_run(workdir ? workdir : ".", nullptr, nullptr, dev ? atoi(dev) : 0); });
 }
 
 ieache_ctx* ieache_ctx_create(const char* cloud_key_path, int device) {
