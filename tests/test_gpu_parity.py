@@ -564,3 +564,27 @@ def _run_file_contract_daemon(ia, tmp_path, sock, operator, bits, a, sa, b, sb):
     tools.alice(tmp_path, sa, bits, a, seed=31)
     tools.alice(tmp_path, sb, bits, b, seed=32, append=True)
     return ia.compute(operator, tmp_path, daemon_socket=sock, failure_size=64 * (4 * 6 + 16))
+
+
+def test_bench_two_rank_flow_on_one_gpu(tmp_path):
+    """The N>1 path of bench.py end to end (key broadcast, batch sharding, max-over-ranks timing, one JSON
+    line from rank 0), rehearsed with CPU collectives so that both ranks can share this box's one GPU."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--batch", "48", "--backend", "gloo", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["batch_per_gpu"] == 48 and out["config"]["parallelism"] == "batch-sharded x2"
+    assert "cpu_baseline" not in out and out["roofline"]["frac"] > 0
