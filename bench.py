@@ -25,6 +25,8 @@ import numpy as np  # noqa: E402
 # SURVEY.md section 8(d) / BASELINE.md section 3: algorithmic bytes per bootstrapped gate
 # = BK n(k+1)l(k+1)N*4 + expected KSK rows N*t*(1-2^-basebit)*(n+1)*4 + LWE I/O 3(n+1)*4
 HBM_PEAK_GBS = 8000.0
+FP64_VALU_PEAK_TFLOPS = 78.6                 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FP64_OPS_PER_GATE = 630 * 3900 * 64          # lane-instructions of the blind rotation per gate at n = 630
 
 WORKLOADS = {
     # name: (circuit kind, bits, default per-GPU batch, BASELINE.json config)
@@ -223,7 +225,13 @@ def main():
                          "cmux_steps_per_launch": p.n / max(1.0, launches_per_gate),
                          "algorithmic_bytes_per_gate": per_gate, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "blind_rotate_share": stats.blind_rotate_ms / max(1e-9, stats.total_ms),
-                         "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms)},
+                         "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms),
+                         # secondary line: BK is shared by all gates in flight, so the kernel's real bound is
+                         # the FP64 vector pipe: ~3 900 FP64-rate instructions per lane and CMux step
+                         "secondary": {"bound": "fp64_valu", "unit": "TFLOP/s-equivalent (1 instr = 2 flop)",
+                                       "achieved": FP64_OPS_PER_GATE * 2e-12 * (achieved * 1e9 / per_gate),
+                                       "peak": FP64_VALU_PEAK_TFLOPS,
+                                       "frac": FP64_OPS_PER_GATE * 2e-12 * (achieved * 1e9 / per_gate) / FP64_VALU_PEAK_TFLOPS}},
         }
         if kind == 4 and bits == 32:
             out["mul32_per_s"] = batch * args.steps * world / elapsed
