@@ -41,8 +41,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 //   s[80:81]        address of the current prefetch position's row 0;  s82 remaining coefficients
 //   s[84 : 84+G/2)  packed digits: s[84 + g/2] holds gate g in bits [16(g&1), +16), digit j at bit 2j
 //   s83            scratch
-// G = 32 needs 216 registers (2 waves per SIMD); G = 16 and 8 need 144 and 108 (3 and 4 waves per
-// SIMD) and are for smaller launches, where more workgroups matter more than fewer row fetches per gate.
+// G = 32 needs 216 registers (2 waves per SIMD); G = 16, 8 and 4 need 144, 108 and 90 (3, 4 and 5 waves
+// per SIMD) and are for smaller launches, where more workgroups matter more than fewer row fetches per gate.
 #define KS_SUB4(GATE, TB)                                                               \
     "v_sub_u32 v[32+4*(" #GATE ")+0], v[32+4*(" #GATE ")+0], v[" #TB "+0]\n\t"         \
     "v_sub_u32 v[32+4*(" #GATE ")+1], v[32+4*(" #GATE ")+1], v[" #TB "+4]\n\t"         \
@@ -54,6 +54,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define KS_GATES8(B, J, TB)                                                                         \
     KS_GATE(B + 0, J, TB) KS_GATE(B + 1, J, TB) KS_GATE(B + 2, J, TB) KS_GATE(B + 3, J, TB)         \
     KS_GATE(B + 4, J, TB) KS_GATE(B + 5, J, TB) KS_GATE(B + 6, J, TB) KS_GATE(B + 7, J, TB)
+#define KS_GATES_G4(J, TB) KS_GATE(0, J, TB) KS_GATE(1, J, TB) KS_GATE(2, J, TB) KS_GATE(3, J, TB)
 #define KS_GATES_G8(J, TB) KS_GATES8(0, J, TB)
 #define KS_GATES_G16(J, TB) KS_GATES8(0, J, TB) KS_GATES8(8, J, TB)
 #define KS_GATES_G32(J, TB) KS_GATES8(0, J, TB) KS_GATES8(8, J, TB) KS_GATES8(16, J, TB) KS_GATES8(24, J, TB)
@@ -97,6 +98,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
     "s_cmp_lg_u32 s82, 0\n\t"                                                                    \
     "s_cbranch_scc1 1b\n\t"                                                                      \
     "s_waitcnt vmcnt(0)\n\t" /* the two positions fetched past the slice (the key buffer is padded for them) */
+#define KS_DIGITS_G4(DG)  "ds_read_b64 v[" #DG ":" #DG "+1], %[lds]\n\t s_waitcnt lgkmcnt(0)\n\t"                         \
+                          "v_readfirstlane_b32 s84, v[" #DG "+0]\n\t v_readfirstlane_b32 s85, v[" #DG "+1]\n\t"
 #define KS_DIGITS_G8(DG)  "ds_read_b128 v[" #DG ":" #DG "+3], %[lds]\n\t s_waitcnt lgkmcnt(0)\n\t" KS_RFL4(DG, 0)
 #define KS_DIGITS_G16(DG) "ds_read_b128 v[" #DG ":" #DG "+3], %[lds]\n\t ds_read_b128 v[" #DG "+4:" #DG "+7], %[lds] offset:16\n\t" \
                           "s_waitcnt lgkmcnt(0)\n\t" KS_RFL4(DG, 0) KS_RFL4(DG, 4)
@@ -190,12 +193,19 @@ __global__ __launch_bounds__(256) void k_keyswitch_sliced(DevKeys K, WorkDesc W,
                      : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[1]), "=&{v[96:127]}"(t0), "=&{v[128:143]}"(t1), [lds] "+v"(lds_addr)
                      : [rb] "s"(rowbase), [ni] "s"(ni), [off1] "v"(off1), [off2] "v"(off2), [off3] "v"(off3), [step] "s"(step)
                      : KS_SGPR_CLOBBERS);
-    } else {
-        static_assert(G == 8, "G is 8, 16 or 32");
+    } else if constexpr (G == 8) {
         v32i t0;
         v16i t1;
         asm volatile(KS_WALK(64, 80, 92, KS_GATES_G8, KS_DIGITS_G8(104), 16)
                      : "+{v[32:63]}"(acc[0]), "=&{v[64:95]}"(t0), "=&{v[96:111]}"(t1), [lds] "+v"(lds_addr)
+                     : [rb] "s"(rowbase), [ni] "s"(ni), [off1] "v"(off1), [off2] "v"(off2), [off3] "v"(off3), [step] "s"(step)
+                     : KS_SGPR_CLOBBERS);
+    } else {
+        static_assert(G == 4, "G is 4, 8, 16 or 32");
+        // accumulators in the low half of acc[0] (v[32:47]); its high half holds the row table
+        v16i t1, t2g4;
+        asm volatile(KS_WALK(48, 64, 76, KS_GATES_G4, KS_DIGITS_G4(88), 8)
+                     : "+{v[32:63]}"(acc[0]), "=&{v[64:79]}"(t1), "=&{v[80:95]}"(t2g4), [lds] "+v"(lds_addr)
                      : [rb] "s"(rowbase), [ni] "s"(ni), [off1] "v"(off1), [off2] "v"(off2), [off3] "v"(off3), [step] "s"(step)
                      : KS_SGPR_CLOBBERS);
     }
@@ -238,7 +248,8 @@ int launch(const Params& p, const DevKeys& K, const WorkDesc& W, int64_t items, 
     if (slice > nco) slice = nco;
     // gates per workgroup: fewer row fetches per gate with 32, more workgroups in flight with 16 / 8
     int g = gates_per_wg;
-    if (g != 8 && g != 16 && g != 32) g = items >= 12288 ? 32 : (items >= 6144 ? 16 : 8);  // measured: 4096 -> 8, 8192 -> 16, 16384 -> 32
+    if (g != 4 && g != 8 && g != 16 && g != 32)  // measured: 1024 -> 4, 4096 -> 8, 8192 -> 16, 16384 -> 32
+        g = items >= 12288 ? 32 : (items >= 6144 ? 16 : (items >= 3072 ? 8 : 4));
     int launches = 0;
     for (int32_t i0 = 0; i0 < nco; i0 += slice) {
         const int32_t i1 = i0 + slice < nco ? i0 + slice : nco;
@@ -246,8 +257,10 @@ int launch(const Params& p, const DevKeys& K, const WorkDesc& W, int64_t items, 
             launch_g<32>(K, W, items, ext, flat_out, i0, i1, nld, stream);
         else if (g == 16)
             launch_g<16>(K, W, items, ext, flat_out, i0, i1, nld, stream);
-        else
+        else if (g == 8)
             launch_g<8>(K, W, items, ext, flat_out, i0, i1, nld, stream);
+        else
+            launch_g<4>(K, W, items, ext, flat_out, i0, i1, nld, stream);
         launches++;
     }
     return launches;

@@ -16,7 +16,7 @@ ref = ctx.debug_keyswitch(u)
 ctx.set_option("ks_batch_min", 1)
 assert np.array_equal(ctx.debug_keyswitch(u), ref), "batch kernel differs"
 ctx.set_option("ks_sliced_min", 1)
-for sl, g in ((0, 0), (7, 8), (64, 16), (1024, 32), (100, 8), (0, 16), (333, 32)):
+for sl, g in ((0, 0), (7, 8), (64, 16), (1024, 32), (100, 8), (0, 16), (333, 32), (0, 4), (9, 4)):
     ctx.set_option("ks_slice", sl)
     ctx.set_option("ks_gates", g)
     out = ctx.debug_keyswitch(u)

@@ -45,7 +45,7 @@ def test_keyswitch_stage_bit_exact(gpu_ctx, n, N):
     assert not out[4, :n].any() and out[4, n] == u[4, N]
     if N % 8 == 0 and n >= 8:  # the hand-scheduled sliced kernel (large launches) on the same edge rows, against the oracle
         ctx.set_option("ks_sliced_min", 1)
-        for gates, sl in ((8, 0), (16, 3), (32, 0)):
+        for gates, sl in ((4, 0), (8, 0), (16, 3), (32, 0)):
             ctx.set_option("ks_gates", gates)
             ctx.set_option("ks_slice", sl)
             assert np.array_equal(ctx.debug_keyswitch(u), out), (gates, sl)
@@ -319,7 +319,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     rng = np.random.default_rng(3)
     bits = rng.integers(0, 2, size=(2, 2304)).astype(np.uint8)
     a, b = kb.enc(bits[0], 41), kb.enc(bits[1], 42)
-    ref = ctx.gates(ia.GATE_AND, a, b)                     # defaults: slice 16, sliced key switch (>= 2048 gates)
+    ref = ctx.gates(ia.GATE_AND, a, b)                     # defaults: slice 16, sliced key switch (>= 1024 gates)
     assert np.array_equal(kb.dec(ref), bits[0] & bits[1])
     for i in (0, 1, 2303):
         assert np.array_equal(kb.ck.gate("and", a[i], b[i]), ref[i])
@@ -343,7 +343,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     ctx.set_option("br_wide_max", 1 << 20)
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
     ctx.set_option("br_wide_max", 256)
-    # key switch: the defaults above took the sliced hand-scheduled kernel (>= 2048 gates); now every other one
+    # key switch: the defaults above took the sliced hand-scheduled kernel (>= 1024 gates); now every other one
     ctx.set_option("ks_sliced_min", 1 << 40)
     ctx.set_option("ks_batch_min", 1 << 40)                # per-gate vectorised key switch
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
@@ -351,13 +351,14 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:37], b[:37]), ref[:37])  # ragged last group of 16
     ctx.set_option("ks_batch_min", 4096)
     ctx.set_option("ks_sliced_min", 1)                     # sliced key switch: 8 / 16 / 32 gates per workgroup,
-    for gates, sl, cnt in ((8, 0, 2304), (16, 5, 2304), (32, 64, 2304), (32, 1024, 37), (8, 3, 1), (0, 0, 2304)):
+    for gates, sl, cnt in ((8, 0, 2304), (16, 5, 2304), (32, 64, 2304), (32, 1024, 37), (8, 3, 1), (4, 0, 2304), (4, 7, 5),
+                           (0, 0, 2304)):
         ctx.set_option("ks_gates", gates)                  # whole walk or ragged slices, ragged last groups
         ctx.set_option("ks_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:cnt], b[:cnt]), ref[:cnt]), (gates, sl, cnt)
     ctx.set_option("ks_gates", 0)
     ctx.set_option("ks_slice", 0)
-    ctx.set_option("ks_sliced_min", 2048)
+    ctx.set_option("ks_sliced_min", 1024)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("ks_gates", 12)
     ctx.force_generic(True)
