@@ -494,7 +494,7 @@ struct Evaluator::Impl {
     bool ks_batch_ok = false;     // gate-batched key switch usable (base == 4, digits fit 16 bits, columns fit 8 waves)
     int64_t ks_batch_min = 4096;  // use it from this many gate instances per launch (one workgroup walk takes ~5 ms)
     bool ks_sliced_ok = false;    // hand-scheduled sliced variant of it usable (t = 8, basebit = 2)
-    int64_t ks_sliced_min = 1024; // ... and used from this many gate instances per launch
+    int64_t ks_sliced_min = 768;  // ... and used from this many gate instances per launch
     int32_t ks_slice = 0;         // coefficients per launch of the sliced key switch; 0 = the whole walk
     int32_t ks_gates = 0;         // gate instances per workgroup there (8 / 16 / 32); 0 = by launch size
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
@@ -648,9 +648,9 @@ void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
     if (!d_->bkf) HIP_CHECK(hipMalloc(&d_->bkf, npoly * 2 * K.M * sizeof(double2)));
     const size_t ks_rows = (size_t)p_.k * p_.N * p_.ks_t * K.ks_base;
     if (!d_->ksk) {
-        // 8 rows of slack: the sliced key switch prefetches two positions past the end of its walk
-        HIP_CHECK(hipMalloc(&d_->ksk, (ks_rows + 8) * K.stride * 4));
-        HIP_CHECK(hipMemsetAsync(d_->ksk + ks_rows * K.stride, 0, (size_t)8 * K.stride * 4, stream_));
+        // 16 rows of slack: the sliced key switch prefetches four positions past the end of its walk
+        HIP_CHECK(hipMalloc(&d_->ksk, (ks_rows + 16) * K.stride * 4));
+        HIP_CHECK(hipMemsetAsync(d_->ksk + ks_rows * K.stride, 0, (size_t)16 * K.stride * 4, stream_));
     }
     K.bkf = d_->bkf;
     K.ksk = d_->ksk;

@@ -31,17 +31,20 @@ namespace {
 
 typedef int v32i __attribute__((ext_vector_type(32)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 // Register plan of the assembly block for G gate instances per workgroup (nothing else may live
-// there while it runs); TB = 32 + 4G, SA = TB + 16, SB = SA + 12, DG = SB + 12:
+// there while it runs); TB = 32 + 4G, stages S0..S3 = TB + 16 + 12k, DG = S3 + 12:
 //   v[32 : 32+4G)   accumulators: gate g, component c at v[32 + 4g + c]
 //   v[TB : TB+16)   row table, component-major: v[TB + 4c + d] = component c of row d (d = 0: zero)
-//   v[SA : SA+12)   staged rows of even positions (r1, r2, r3);  v[SB : SB+12) of odd positions
+//   v[Sk : Sk+12)   rows (r1, r2, r3) of the positions = k mod 4, fetched four positions ahead
 //   v[DG : DG+G/2)  packed digits of one coefficient for the G gates, as read from LDS
 //   s[80:81]        address of the current prefetch position's row 0;  s82 remaining coefficients
 //   s[84 : 84+G/2)  packed digits: s[84 + g/2] holds gate g in bits [16(g&1), +16), digit j at bit 2j
 //   s83            scratch
-// G = 32 needs 216 registers (2 waves per SIMD); G = 16, 8 and 4 need 144, 108 and 90 (3, 4 and 5 waves
+// G = 32 needs 240 registers (2 waves per SIMD); G = 16, 8 and 4 need 168, 132 and 114 (3, 3 and 4 waves
 // per SIMD) and are for smaller launches, where more workgroups matter more than fewer row fetches per gate.
 #define KS_SUB4(GATE, TB)                                                               \
     "v_sub_u32 v[32+4*(" #GATE ")+0], v[32+4*(" #GATE ")+0], v[" #TB "+0]\n\t"         \
@@ -58,10 +61,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define KS_GATES_G8(J, TB) KS_GATES8(0, J, TB)
 #define KS_GATES_G16(J, TB) KS_GATES8(0, J, TB) KS_GATES8(8, J, TB)
 #define KS_GATES_G32(J, TB) KS_GATES8(0, J, TB) KS_GATES8(8, J, TB) KS_GATES8(16, J, TB) KS_GATES8(24, J, TB)
-// one position: wait for its rows, move them into the table, refill the stage with position + 2,
+// one position: wait for its rows, move them into the table, refill the stage with position + 4,
 // then let every gate subtract the row its digit selects
 #define KS_POSITION(J, S, TB, GATES)                                                           \
-    "s_waitcnt vmcnt(3)\n\t"                                                                   \
+    "s_waitcnt vmcnt(9)\n\t"                                                                   \
     "v_mov_b32 v[" #TB "+1], v[" #S "+0]\n\t v_mov_b32 v[" #TB "+5], v[" #S "+1]\n\t"        \
     "v_mov_b32 v[" #TB "+9], v[" #S "+2]\n\t v_mov_b32 v[" #TB "+13], v[" #S "+3]\n\t"       \
     "v_mov_b32 v[" #TB "+2], v[" #S "+4]\n\t v_mov_b32 v[" #TB "+6], v[" #S "+5]\n\t"        \
@@ -77,27 +80,25 @@ typedef int v16i __attribute__((ext_vector_type(16)));
     "v_readfirstlane_b32 s[84+" #K "+0], v[" #DG "+" #K "+0]\n\t v_readfirstlane_b32 s[84+" #K "+1], v[" #DG "+" #K "+1]\n\t" \
     "v_readfirstlane_b32 s[84+" #K "+2], v[" #DG "+" #K "+2]\n\t v_readfirstlane_b32 s[84+" #K "+3], v[" #DG "+" #K "+3]\n\t"
 // the whole walk over the coefficients of a slice; DIGITS reads one coefficient's digits into s[84...]
-#define KS_WALK(TB, SA, SB, GATES, DIGITS, LDSTEP)                                              \
+#define KS_LOAD3(S)                                                                             \
+    "global_load_dwordx4 v[" #S "+0:" #S "+3], %[off1], s[80:81]\n\t"                         \
+    "global_load_dwordx4 v[" #S "+4:" #S "+7], %[off2], s[80:81]\n\t"                         \
+    "global_load_dwordx4 v[" #S "+8:" #S "+11], %[off3], s[80:81]\n\t"                        \
+    "s_add_u32 s80, s80, %[step]\n\t s_addc_u32 s81, s81, 0\n\t"
+#define KS_WALK(TB, S0, S1, S2, S3, GATES, DIGITS, LDSTEP)                                      \
     "s_mov_b64 s[80:81], %[rb]\n\t"                                                             \
     "s_mov_b32 s82, %[ni]\n\t"                                                                  \
     "v_mov_b32 v[" #TB "+0], 0\n\t v_mov_b32 v[" #TB "+4], 0\n\t v_mov_b32 v[" #TB "+8], 0\n\t v_mov_b32 v[" #TB "+12], 0\n\t" \
-    "global_load_dwordx4 v[" #SA "+0:" #SA "+3], %[off1], s[80:81]\n\t"                        \
-    "global_load_dwordx4 v[" #SA "+4:" #SA "+7], %[off2], s[80:81]\n\t"                        \
-    "global_load_dwordx4 v[" #SA "+8:" #SA "+11], %[off3], s[80:81]\n\t"                       \
-    "s_add_u32 s80, s80, %[step]\n\t s_addc_u32 s81, s81, 0\n\t"                                \
-    "global_load_dwordx4 v[" #SB "+0:" #SB "+3], %[off1], s[80:81]\n\t"                        \
-    "global_load_dwordx4 v[" #SB "+4:" #SB "+7], %[off2], s[80:81]\n\t"                        \
-    "global_load_dwordx4 v[" #SB "+8:" #SB "+11], %[off3], s[80:81]\n\t"                       \
-    "s_add_u32 s80, s80, %[step]\n\t s_addc_u32 s81, s81, 0\n\t"                                \
+    KS_LOAD3(S0) KS_LOAD3(S1) KS_LOAD3(S2) KS_LOAD3(S3)                                          \
     "1:\n\t" DIGITS                                                                              \
     "v_add_u32 %[lds], " #LDSTEP ", %[lds]\n\t"                                                  \
     "s_nop 3\n\t" /* VALU wrote the SGPRs the s_bfe_u32 below reads */                           \
-    KS_POSITION(0, SA, TB, GATES) KS_POSITION(1, SB, TB, GATES) KS_POSITION(2, SA, TB, GATES) KS_POSITION(3, SB, TB, GATES) \
-    KS_POSITION(4, SA, TB, GATES) KS_POSITION(5, SB, TB, GATES) KS_POSITION(6, SA, TB, GATES) KS_POSITION(7, SB, TB, GATES) \
+    KS_POSITION(0, S0, TB, GATES) KS_POSITION(1, S1, TB, GATES) KS_POSITION(2, S2, TB, GATES) KS_POSITION(3, S3, TB, GATES) \
+    KS_POSITION(4, S0, TB, GATES) KS_POSITION(5, S1, TB, GATES) KS_POSITION(6, S2, TB, GATES) KS_POSITION(7, S3, TB, GATES) \
     "s_sub_u32 s82, s82, 1\n\t"                                                                  \
     "s_cmp_lg_u32 s82, 0\n\t"                                                                    \
     "s_cbranch_scc1 1b\n\t"                                                                      \
-    "s_waitcnt vmcnt(0)\n\t" /* the two positions fetched past the slice (the key buffer is padded for them) */
+    "s_waitcnt vmcnt(0)\n\t" /* the four positions fetched past the slice (the key buffer is padded for them) */
 #define KS_DIGITS_G4(DG)  "ds_read_b64 v[" #DG ":" #DG "+1], %[lds]\n\t s_waitcnt lgkmcnt(0)\n\t"                         \
                           "v_readfirstlane_b32 s84, v[" #DG "+0]\n\t v_readfirstlane_b32 s85, v[" #DG "+1]\n\t"
 #define KS_DIGITS_G8(DG)  "ds_read_b128 v[" #DG ":" #DG "+3], %[lds]\n\t s_waitcnt lgkmcnt(0)\n\t" KS_RFL4(DG, 0)
@@ -178,37 +179,34 @@ __global__ __launch_bounds__(256) void k_keyswitch_sliced(DevKeys K, WorkDesc W,
     uint32_t off1 = (uint32_t)ccol * 16u + rowbytes, off2 = off1 + rowbytes, off3 = off2 + rowbytes;
     const uint32_t step = 4u * rowbytes;
     uint32_t lds_addr = (uint32_t)(uintptr_t)dw;  // LDS byte address (the low 32 bits of a __shared__ pointer)
-    // scratch register ranges are claimed through pinned dummy outputs (t0, t1)
+    // scratch register ranges are claimed through pinned dummy outputs
+#define KS_IO [lds] "+v"(lds_addr) : [rb] "s"(rowbase), [ni] "s"(ni), [off1] "v"(off1), [off2] "v"(off2), [off3] "v"(off3), [step] "s"(step) : KS_SGPR_CLOBBERS
     if constexpr (G == 32) {
         v32i t0, t1;
-        asm volatile(KS_WALK(160, 176, 188, KS_GATES_G32, KS_DIGITS_G32(200), 64)
+        v16i t2;
+        asm volatile(KS_WALK(160, 176, 188, 200, 212, KS_GATES_G32, KS_DIGITS_G32(224), 64)
                      : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[1]), "+{v[96:127]}"(acc[2]), "+{v[128:159]}"(acc[3]),
-                       "=&{v[160:191]}"(t0), "=&{v[192:223]}"(t1), [lds] "+v"(lds_addr)
-                     : [rb] "s"(rowbase), [ni] "s"(ni), [off1] "v"(off1), [off2] "v"(off2), [off3] "v"(off3), [step] "s"(step)
-                     : KS_SGPR_CLOBBERS);
+                       "=&{v[160:191]}"(t0), "=&{v[192:223]}"(t1), "=&{v[224:239]}"(t2), KS_IO);
     } else if constexpr (G == 16) {
-        v32i t0;
-        v16i t1;
-        asm volatile(KS_WALK(96, 112, 124, KS_GATES_G16, KS_DIGITS_G16(136), 32)
-                     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[1]), "=&{v[96:127]}"(t0), "=&{v[128:143]}"(t1), [lds] "+v"(lds_addr)
-                     : [rb] "s"(rowbase), [ni] "s"(ni), [off1] "v"(off1), [off2] "v"(off2), [off3] "v"(off3), [step] "s"(step)
-                     : KS_SGPR_CLOBBERS);
+        v32i t0, t1;
+        v8i t2;
+        asm volatile(KS_WALK(96, 112, 124, 136, 148, KS_GATES_G16, KS_DIGITS_G16(160), 32)
+                     : "+{v[32:63]}"(acc[0]), "+{v[64:95]}"(acc[1]), "=&{v[96:127]}"(t0), "=&{v[128:159]}"(t1), "=&{v[160:167]}"(t2), KS_IO);
     } else if constexpr (G == 8) {
-        v32i t0;
-        v16i t1;
-        asm volatile(KS_WALK(64, 80, 92, KS_GATES_G8, KS_DIGITS_G8(104), 16)
-                     : "+{v[32:63]}"(acc[0]), "=&{v[64:95]}"(t0), "=&{v[96:111]}"(t1), [lds] "+v"(lds_addr)
-                     : [rb] "s"(rowbase), [ni] "s"(ni), [off1] "v"(off1), [off2] "v"(off2), [off3] "v"(off3), [step] "s"(step)
-                     : KS_SGPR_CLOBBERS);
+        v32i t0, t1;
+        v4i t2;
+        asm volatile(KS_WALK(64, 80, 92, 104, 116, KS_GATES_G8, KS_DIGITS_G8(128), 16)
+                     : "+{v[32:63]}"(acc[0]), "=&{v[64:95]}"(t0), "=&{v[96:127]}"(t1), "=&{v[128:131]}"(t2), KS_IO);
     } else {
         static_assert(G == 4, "G is 4, 8, 16 or 32");
         // accumulators in the low half of acc[0] (v[32:47]); its high half holds the row table
-        v16i t1, t2g4;
-        asm volatile(KS_WALK(48, 64, 76, KS_GATES_G4, KS_DIGITS_G4(88), 8)
-                     : "+{v[32:63]}"(acc[0]), "=&{v[64:79]}"(t1), "=&{v[80:95]}"(t2g4), [lds] "+v"(lds_addr)
-                     : [rb] "s"(rowbase), [ni] "s"(ni), [off1] "v"(off1), [off2] "v"(off2), [off3] "v"(off3), [step] "s"(step)
-                     : KS_SGPR_CLOBBERS);
+        v32i t0;
+        v16i t1;
+        v2i t2;
+        asm volatile(KS_WALK(48, 64, 76, 88, 100, KS_GATES_G4, KS_DIGITS_G4(112), 8)
+                     : "+{v[32:63]}"(acc[0]), "=&{v[64:95]}"(t0), "=&{v[96:111]}"(t1), "=&{v[112:113]}"(t2), KS_IO);
     }
+#undef KS_IO
     if (active) {
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -248,8 +246,8 @@ int launch(const Params& p, const DevKeys& K, const WorkDesc& W, int64_t items, 
     if (slice > nco) slice = nco;
     // gates per workgroup: fewer row fetches per gate with 32, more workgroups in flight with 16 / 8
     int g = gates_per_wg;
-    if (g != 4 && g != 8 && g != 16 && g != 32)  // measured: 1024 -> 4, 4096 -> 8, 8192 -> 16, 16384 -> 32
-        g = items >= 12288 ? 32 : (items >= 6144 ? 16 : (items >= 3072 ? 8 : 4));
+    if (g != 4 && g != 8 && g != 16 && g != 32)  // measured (profiles/r1_v8_kernel_microbench.txt): 1024 -> 4, 2048-4096 -> 8, 8192 -> 16
+        g = items >= 14336 ? 32 : (items >= 5120 ? 16 : (items >= 1536 ? 8 : 4));
     int launches = 0;
     for (int32_t i0 = 0; i0 < nco; i0 += slice) {
         const int32_t i1 = i0 + slice < nco ? i0 + slice : nco;
