@@ -43,7 +43,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 //   v[DG : DG+G/2)  packed digits of one coefficient for the G gates, as read from LDS
 //   s[80:81]        address of the current prefetch position's row 0;  s82 remaining coefficients
 //   s[84 : 84+G/2)  packed digits: s[84 + g/2] holds gate g in bits [16(g&1), +16), digit j at bit 2j
-//   s83            scratch
+//   s83            scratch;  s79 saved M0
 // G = 32 needs 240 registers (2 waves per SIMD); G = 16, 8 and 4 need 168, 132 and 114 (3, 3 and 4 waves
 // per SIMD) and are for smaller launches, where more workgroups matter more than fewer row fetches per gate.
 #define KS_SUB4(GATE, TB)                                                               \
@@ -86,6 +86,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
     "global_load_dwordx4 v[" #S "+8:" #S "+11], %[off3], s[80:81]\n\t"                        \
     "s_add_u32 s80, s80, %[step]\n\t s_addc_u32 s81, s81, 0\n\t"
 #define KS_WALK(TB, S0, S1, S2, S3, GATES, DIGITS, LDSTEP)                                      \
+    "s_mov_b32 s79, m0\n\t" /* the index mode below writes M0 */                                \
     "s_mov_b64 s[80:81], %[rb]\n\t"                                                             \
     "s_mov_b32 s82, %[ni]\n\t"                                                                  \
     "v_mov_b32 v[" #TB "+0], 0\n\t v_mov_b32 v[" #TB "+4], 0\n\t v_mov_b32 v[" #TB "+8], 0\n\t v_mov_b32 v[" #TB "+12], 0\n\t" \
@@ -98,7 +99,8 @@ typedef int v2i __attribute__((ext_vector_type(2)));
     "s_sub_u32 s82, s82, 1\n\t"                                                                  \
     "s_cmp_lg_u32 s82, 0\n\t"                                                                    \
     "s_cbranch_scc1 1b\n\t"                                                                      \
-    "s_waitcnt vmcnt(0)\n\t" /* the four positions fetched past the slice (the key buffer is padded for them) */
+    "s_waitcnt vmcnt(0)\n\t" /* the four positions fetched past the slice (the key buffer is padded for them) */ \
+    "s_mov_b32 m0, s79\n\t"
 #define KS_DIGITS_G4(DG)  "ds_read_b64 v[" #DG ":" #DG "+1], %[lds]\n\t s_waitcnt lgkmcnt(0)\n\t"                         \
                           "v_readfirstlane_b32 s84, v[" #DG "+0]\n\t v_readfirstlane_b32 s85, v[" #DG "+1]\n\t"
 #define KS_DIGITS_G8(DG)  "ds_read_b128 v[" #DG ":" #DG "+3], %[lds]\n\t s_waitcnt lgkmcnt(0)\n\t" KS_RFL4(DG, 0)
@@ -107,7 +109,7 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #define KS_DIGITS_G32(DG) "ds_read_b128 v[" #DG ":" #DG "+3], %[lds]\n\t ds_read_b128 v[" #DG "+4:" #DG "+7], %[lds] offset:16\n\t" \
                           "ds_read_b128 v[" #DG "+8:" #DG "+11], %[lds] offset:32\n\t ds_read_b128 v[" #DG "+12:" #DG "+15], %[lds] offset:48\n\t" \
                           "s_waitcnt lgkmcnt(0)\n\t" KS_RFL4(DG, 0) KS_RFL4(DG, 4) KS_RFL4(DG, 8) KS_RFL4(DG, 12)
-#define KS_SGPR_CLOBBERS "memory", "scc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", \
+#define KS_SGPR_CLOBBERS "memory", "scc", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", \
                          "s94", "s95", "s96", "s97", "s98", "s99"
 
 // LDS: dw [i1 - i0][G] u16 (packed digits)
