@@ -4,16 +4,23 @@
   python bench.py --gpus N --steps K --warmup W [--workload add16|mul32|...] [--batch B]
 
 One "step" = one pass of a whole circuit (every level, every gate) over one
-batch of expressions whose ciphertexts are already resident in HBM.  Default
-workload = BASELINE.json configs[1]: 16-bit ADD, batch 4096 per GPU.  For N>1
-launch through torch.distributed.run (one rank per GPU); expressions shard
-across ranks with no data-path collective (weak scaling: the per-GPU batch is
-fixed), after a one-time RCCL broadcast of the bootstrapping / key-switch key.
-Rank 0 prints ONE JSON line.
+batch of expressions whose ciphertexts are already resident in HBM.  The timed
+K steps run the primary workload = BASELINE.json configs[1]: 16-bit ADD, batch
+4096 per GPU.  The default invocation then adds a second timed leg on the same
+resident key: ONE full pass of configs[2] (32-bit shift-add MUL, batch 1024 per
+GPU, every product decrypt-checked) -> the `mul32` object of the JSON line
+(gate ops/s, encrypted 32-bit MUL/s, its own roofline), and one pass of the
+opt-in constant-folded multiplier (`mul32.folded`).  For N>1 launch through
+torch.distributed.run (one rank per GPU); expressions shard across ranks with
+no data-path collective (weak scaling: the per-GPU batch is fixed), after a
+one-time RCCL broadcast of the bootstrapping / key-switch key.  Rank 0 prints
+ONE JSON line.
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -22,43 +29,112 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-# SURVEY.md section 8(d) / BASELINE.md section 3: algorithmic bytes per bootstrapped gate
-# = BK n(k+1)l(k+1)N*4 + expected KSK rows N*t*(1-2^-basebit)*(n+1)*4 + LWE I/O 3(n+1)*4
-HBM_PEAK_GBS = 8000.0
-FP64_VALU_PEAK_TFLOPS = 78.6                 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-FP64_OPS_PER_GATE = 630 * 3900 * 64          # lane-instructions of the blind rotation per gate at n = 630
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6          # 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+LANES, FLOP_PER_INST = 64, 2          # one wave-instruction = 64 lanes; priced as an FMA (2 flop) like the peak
 
 WORKLOADS = {
     # name: (circuit kind, bits, default per-GPU batch, BASELINE.json config)
     "add16": (1, 16, 4096, "16-bit ADD, batch 4096 ciphertext pairs, 1xMI355X (level-batched bootstraps)"),
     "add32": (1, 32, 1024, "32-bit ADD"),
     "mul32": (4, 32, 1024, "32-bit shift-add MUL, batch 1024, 1xMI355X"),
+    "muladd32": (5, 32, 1024, "32-bit 3-operand a*b+c (AC058.pdf Fig. 7 A+B*C)"),
     "muladd64": (5, 64, 128, "64-bit 3-operand a*b+c, batch 1024, sharded across 8xMI355X"),
     "mul128": (4, 128, 1024, "128-bit multi-precision MUL, batch 8192, 8xMI355X"),
 }
 
 
-def algorithmic_bytes_per_gate(p):
+def algorithmic_bytes(p):
+    """SURVEY.md 8(d) / BASELINE.md 3: BK n(k+1)l(k+1)N*4, expected KSK rows N*t*(1-2^-basebit)*(n+1)*4, LWE I/O 3(n+1)*4"""
     bk = p.n * (p.k + 1) * p.l * (p.k + 1) * p.N * 4
     ksk = p.k * p.N * p.ks_t * (1.0 - 2.0 ** -p.ks_basebit) * (p.n + 1) * 4
     io = 3 * (p.n + 1) * 4
-    return bk + ksk + io
+    return bk, ksk, io
+
+
+def pmc_counters(kernel_variant):
+    """Committed PMC evidence for the dominant kernel (rocprofv3 cannot run inside this process):
+    profiles/traffic.json names the launch geometry and the summary file the counters come from
+    (scripts/pmc_passes.sh); SQ_INSTS_VALU is parsed from that summary."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(kernel_variant)
+        if not tj:
+            return None
+        out = {"hbm_bytes_per_gate_step": tj["hbm_bytes_per_gate_step"], "l2_hit_rate": tj.get("l2_hit_rate"),
+               "source": tj.get("pmc_summary", tj.get("source"))}
+        summ = tj.get("pmc_summary")
+        if summ:
+            for line in open(os.path.join(ROOT, summ)):
+                m = re.match(r"BR SQ_INSTS_VALU\s+n=\d+ avg=([0-9.e+]+)", line)
+                if m:
+                    out["valu_insts_per_gate_step"] = float(m.group(1)) / (tj["gates_per_launch"] * tj["cmux_steps_per_launch"])
+        return out
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def roofline(p, stats, gate_rate, pmc):
+    """The record for one timed leg.  Primary bound: FP64 vector issue of the blind rotation (BK is shared
+    by every gate of a launch out of L2, so HBM is not what limits it: see hbm_model.reuse_factor).
+    hbm_model is SURVEY 8(d)'s streaming-model figure, priced end to end on the leg's own rate."""
+    bk_b, ksk_b, io_b = algorithmic_bytes(p)
+    per_gate = bk_b + ksk_b + io_b
+    br_avg_ms = stats.blind_rotate_ms / max(1, stats.blind_rotate_launches)
+    ks_avg_ms = stats.keyswitch_ms / max(1, stats.keyswitch_launches)
+    gates_per_launch = stats.bootstraps / max(1, stats.chunks)
+    launches_per_gate = stats.blind_rotate_launches / max(1, stats.chunks)
+    steps_per_launch = p.n / max(1.0, launches_per_gate)
+    br_gate_rate = stats.bootstraps / max(1e-9, stats.blind_rotate_ms * 1e-3)   # gates/s of the blind rotation alone
+    ks_gate_rate = stats.bootstraps / max(1e-9, stats.keyswitch_ms * 1e-3)
+    insts = pmc.get("valu_insts_per_gate_step") if pmc else None
+    traffic = pmc["hbm_bytes_per_gate_step"] * gates_per_launch * steps_per_launch if pmc else None
+    out = {"kernel": "k_blind_rotate_w2", "avg_launch_ms": br_avg_ms, "gates_per_launch": gates_per_launch,
+           "cmux_steps_per_launch": steps_per_launch, "traffic": traffic,
+           "blind_rotate_share": stats.blind_rotate_ms / max(1e-9, stats.total_ms),
+           "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms)}
+    if insts:
+        flop_per_gate = insts * p.n * LANES * FLOP_PER_INST
+        out.update({"bound": "fp64_valu", "unit": "TFLOP/s",
+                    "achieved": br_gate_rate * flop_per_gate * 1e-12, "peak": FP64_VALU_PEAK_TFLOPS,
+                    "frac": br_gate_rate * flop_per_gate * 1e-12 / FP64_VALU_PEAK_TFLOPS,
+                    "valu_insts_per_gate": insts * p.n, "valu_insts_source": pmc.get("source"),
+                    "note": "achieved = blind-rotation gates/s (HIP events over its launches) x SQ_INSTS_VALU per gate x 64 lanes x 2 flop; "
+                            "100 %% = %.0f gates/s per GPU at 2.4 GHz" % (FP64_VALU_PEAK_TFLOPS * 1e12 / flop_per_gate)})
+    else:
+        out.update({"bound": "fp64_valu", "unit": "TFLOP/s", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "frac": None,
+                    "note": "no committed SQ_INSTS_VALU for this kernel variant"})
+    measured_gbs = (traffic / (br_avg_ms * 1e-3) / 1e9) if (traffic and br_avg_ms > 0) else None
+    alg_launch = per_gate * gates_per_launch * steps_per_launch / p.n
+    out["hbm_model"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "achieved": gate_rate * per_gate / 1e9, "frac": gate_rate * per_gate / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_gate": per_gate, "algorithmic_bytes_per_launch": alg_launch,
+                        "measured_hbm_bytes_per_launch": traffic, "measured_hbm_GBps": measured_gbs,
+                        "reuse_factor": (alg_launch / traffic) if traffic else None,
+                        "note": "streaming model (every gate streams BK and its KSK rows once), priced end to end on this leg's gate rate; "
+                                "measured = FETCH_SIZE x2 + WRITE_SIZE of the blind-rotation launches (PMC, gfx950 correction)"}
+    out["per_kernel"] = {
+        "blind_rotate": {"algorithmic_bytes_per_gate": bk_b, "achieved_GBps": br_gate_rate * bk_b / 1e9,
+                         "frac_of_hbm": br_gate_rate * bk_b / 1e9 / HBM_PEAK_GBS, "gates_per_s": br_gate_rate, "avg_launch_ms": br_avg_ms},
+        "keyswitch": {"algorithmic_bytes_per_gate": ksk_b, "achieved_GBps": ks_gate_rate * ksk_b / 1e9,
+                      "frac_of_hbm": ks_gate_rate * ksk_b / 1e9 / HBM_PEAK_GBS, "gates_per_s": ks_gate_rate, "avg_launch_ms": ks_avg_ms}}
+    return out
 
 
 def cpu_baseline(p, keys, seconds=12.0):
     """Times the CPU oracle's gate bootstrap on this host (rank 0, N=1 only).
 
-    kind "port": the reference binary cannot be built (libtfhe absent).  The
-    number quoted is the oracle's FP64-FFT back-end, which follows libtfhe's own
-    algorithm (the exact-integer back-end used for parity is ~10x slower and is
-    reported beside it)."""
+    kind "port": the reference binary cannot be built (libtfhe absent).  `value` is the oracle's
+    FP64-FFT back-end, which follows libtfhe's own algorithm, on ONE thread -- how the reference
+    effectively runs (its OpenMP pragmas are inert).  `all_cores` is the same back-end with
+    independent gates spread over every host core; the exact-integer
+    back-end used for parity is reported beside them."""
     from oracle import oracle as O
     from ieache_amd import tools
     ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, keys["bk"], keys["ksk"])
     a = tools.encrypt_bits(p, keys["lwe_key"], np.array([1, 0], dtype=np.uint8), 1)
     b = tools.encrypt_bits(p, keys["lwe_key"], np.array([1, 1], dtype=np.uint8), 2)
     res = {}
-    for mode, name, budget in ((O.POLYMUL_FFT, "fft", seconds * 0.7), (O.POLYMUL_NTT, "exact", seconds * 0.3)):
+    for mode, name, budget in ((O.POLYMUL_FFT, "fft", seconds * 0.45), (O.POLYMUL_NTT, "exact", seconds * 0.2)):
         ck.set_polymul(mode)
         ck.gate("and", a[0], b[0])  # warm-up (also builds the FFT-domain key once)
         n, t0 = 0, time.perf_counter()
@@ -68,12 +144,84 @@ def cpu_baseline(p, keys, seconds=12.0):
         res[name] = (n, time.perf_counter() - t0)
     n, dt = res["fft"]
     ne, dte = res["exact"]
+    # all host cores: a batch of independent gates sized for ~0.35 x `seconds`
+    cores = O.max_threads()
+    ck.set_polymul(O.POLYMUL_FFT)
+    count = max(cores, int(n / dt * cores * seconds * 0.35))
+    reps = (count + 1) // 2
+    A = np.ascontiguousarray(np.tile(a, (reps, 1))[:count])
+    B = np.ascontiguousarray(np.tile(b, (reps, 1))[:count])
+    t0 = time.perf_counter()
+    ck.gates_batch("and", A, B, threads=0)
+    dta = time.perf_counter() - t0
+    probe = subprocess.run("ldconfig -p | grep -i tfhe", shell=True, capture_output=True, text=True).stdout.strip()
     return {
         "value": n / dt, "unit": "bootstrapped gate ops/s", "cores": 1, "kind": "port",
         "sample": "%d AND/XOR gates (n=%d,N=%d) in %.1f s with the oracle's FP64-FFT back-end (libtfhe's algorithm), "
                   "1 thread as the reference runs (its OpenMP pragmas are inert); exact-integer back-end: %.2f gates/s"
                   % (n, p.n, p.N, dt, ne / dte),
+        "all_cores": {"value": count / dta, "cores": cores, "sample": "%d independent AND gates in %.1f s, OpenMP over gates, same back-end" % (count, dta)},
+        "real_libtfhe": ("found by ldconfig but not timed: %s" % probe) if probe else "unavailable on this host (ldconfig -p | grep tfhe: nothing)",
     }
+
+
+def make_inputs(ia, tools, torch, ctx, p, lwe_key, kind, bits, batch, rank, dev, seed_base):
+    """Synthetic inputs: fresh encryptions of uniform random operands (seeded per rank), edge operands in slots 0-3."""
+    info = ia.circuit_info(kind, bits)
+    rng = np.random.default_rng(seed_base + rank)
+    inb = rng.integers(0, 2, size=(batch, info.n_inputs), dtype=np.uint8)
+    inb[:, 2 * bits:2 * bits + 32] = 0  # the carry word is always 0 (alice.c:147-149)
+    if batch >= 4:  # SURVEY 8d: 0, 1, 2^w-1, process.c's 2^(w-2)
+        for slot, v in enumerate((0, 1, (1 << bits) - 1, 1 << (bits - 2))):
+            inb[slot, :bits] = tools.int_to_bits(v, bits)
+            inb[slot, bits:2 * bits] = tools.int_to_bits(v, bits)
+    stride = ctx.lwe_stride
+    d_in = torch.zeros((batch, info.n_inputs, stride), dtype=torch.int32, device=dev)
+    rows_per = max(1, (1 << 26) // (info.n_inputs * (p.n + 1) * 4))
+    for s in range(0, batch, rows_per):  # stream the encryption through host memory in <=64 MiB pieces
+        e = min(batch, s + rows_per)
+        ct = tools.encrypt_bits(p, lwe_key, inb[s:e], 7777 + seed_base + 131 * rank + s)
+        d_in[s:e, :, :p.n + 1] = torch.from_numpy(ct).to(dev)
+        del ct
+    d_out = torch.zeros((batch, info.n_outputs, stride), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    return info, inb, d_in, d_out
+
+
+def check_outputs(tools, p, lwe_key, kind, bits, inb, d_out, rank):
+    """Every expression of the batch must decrypt to the integer result (P1 at full size)."""
+    batch = inb.shape[0]
+    for s0 in range(0, batch, 512):
+        e0 = min(batch, s0 + 512)
+        dec = tools.decrypt_bits(p, lwe_key, d_out[s0:e0, :, :p.n + 1].cpu().numpy())
+        for e in range(s0, e0):
+            a = tools.bits_to_int(inb[e, :bits])
+            b = tools.bits_to_int(inb[e, bits:2 * bits])
+            exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 3: (b - a) % (1 << bits), 4: a * b}.get(kind)
+            if kind == 5:
+                exp = (a * b + tools.bits_to_int(inb[e, 2 * bits + 32:])) % (1 << (2 * bits))
+            assert tools.bits_to_int(dec[e - s0]) == exp, "rank %d: expression %d decrypts wrong" % (rank, e)
+
+
+def timed(torch, dist, world, dev, backend, fn):
+    """barrier + synchronize on both sides, MAX over ranks"""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
+    return elapsed, per_rank
 
 
 def main():
@@ -84,8 +232,12 @@ def main():
     ap.add_argument("--workload", default="add16", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="expressions per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--mul32-leg", default="auto", choices=["auto", "on", "off"],
+                    help="second timed leg: one pass of mul32 x --mul32-batch (auto: on for the default workload at its default batch)")
+    ap.add_argument("--mul32-batch", type=int, default=1024)
+    ap.add_argument("--no-folded", action="store_true", help="skip the constant-folded pass of the mul32 leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 flow with CPU collectives (ranks may then share one GPU)")
     args = ap.parse_args()
@@ -108,7 +260,6 @@ def main():
     kind, bits, def_batch, config_name = WORKLOADS[args.workload]
     batch = args.batch or def_batch
     p = ia.default_params()  # n=630 N=1024 l=3 Bgbit=7 t=8 basebit=2
-    info = ia.circuit_info(kind, bits)
 
     # ---- keys: generated once on rank 0 (keygen.c seeds), broadcast over RCCL/xGMI ----
     keys = tools.keygen_raw(p, (314, 1592, 657)) if rank == 0 else None
@@ -123,86 +274,64 @@ def main():
     del d_bk, d_ksk
     if args.chunk:
         ctx.set_chunk(args.chunk)
+    pmc = pmc_counters(ctx.kernel_variant)
 
-    # ---- synthetic inputs: fresh encryptions of uniform random operands (seeded per rank) ----
-    rng = np.random.default_rng(1000 + rank)
-    inb = rng.integers(0, 2, size=(batch, info.n_inputs), dtype=np.uint8)
-    inb[:, 2 * bits:2 * bits + 32] = 0  # the carry word is always 0 (alice.c:147-149)
-    if batch >= 4:  # edge operands in slots 0-3: 0, 1, 2^w-1, process.c's 2^(w-2)
-        for slot, v in enumerate((0, 1, (1 << bits) - 1, 1 << (bits - 2))):
-            inb[slot, :bits] = tools.int_to_bits(v, bits)
-            inb[slot, bits:2 * bits] = tools.int_to_bits(v, bits)
-    stride = ctx.lwe_stride
-    d_in = torch.zeros((batch, info.n_inputs, stride), dtype=torch.int32, device=dev)
-    rows_per = max(1, (1 << 26) // (info.n_inputs * (p.n + 1) * 4))
-    for s in range(0, batch, rows_per):  # stream the encryption through host memory in <=64 MiB pieces
-        e = min(batch, s + rows_per)
-        ct = tools.encrypt_bits(p, lwe_key, inb[s:e], 7777 + 131 * rank + s)
-        d_in[s:e, :, :p.n + 1] = torch.from_numpy(ct).to(dev)
-        del ct
-    d_out = torch.zeros((batch, info.n_outputs, stride), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
+    # ---- primary leg ----
+    info, inb, d_in, d_out = make_inputs(ia, tools, torch, ctx, p, lwe_key, kind, bits, batch, rank, dev, 1000)
 
     def step(stats=None):
         ctx.eval_batch_device(kind, bits, batch, d_in.data_ptr(), d_out.data_ptr(), stats)
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):  # at least one untimed pass: its outputs are what gets checked
         step()
-    # correctness of what is being timed: decrypt a few expressions
-    if args.warmup == 0:
-        step()
-    # every expression of the batch must decrypt to the integer result (P1 at full size)
-    for s0 in range(0, batch, 512):
-        e0 = min(batch, s0 + 512)
-        dec = tools.decrypt_bits(p, lwe_key, d_out[s0:e0, :, :p.n + 1].cpu().numpy())
-        for e in range(s0, e0):
-            a = tools.bits_to_int(inb[e, :bits])
-            b = tools.bits_to_int(inb[e, bits:2 * bits])
-            exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 3: (b - a) % (1 << bits), 4: a * b}.get(kind)
-            if kind == 5:
-                exp = (a * b + tools.bits_to_int(inb[e, 2 * bits + 32:])) % (1 << (2 * bits))
-            assert tools.bits_to_int(dec[e - s0]) == exp, "rank %d: expression %d decrypts wrong" % (rank, e)
+    check_outputs(tools, p, lwe_key, kind, bits, inb, d_out, rank)
 
     stats = ia.Stats()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(stats)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, per_rank = timed(torch, dist, world, dev, args.backend, lambda: [step(stats) for _ in range(args.steps)])
+    del d_in, d_out
+
+    # ---- second leg: BASELINE configs[2], the metric's "encrypted 32-bit MUL/sec" ----
+    mul_leg = None
+    want_mul = args.mul32_leg == "on" or (args.mul32_leg == "auto" and args.workload == "add16" and not args.batch)
+    if want_mul:
+        mb = args.mul32_batch
+        minfo, minb, md_in, md_out = make_inputs(ia, tools, torch, ctx, p, lwe_key, 4, 32, mb, rank, dev, 5000)
+        mst = ia.Stats()
+        m_elapsed, m_per_rank = timed(torch, dist, world, dev, args.backend,
+                                      lambda: ctx.eval_batch_device(4, 32, mb, md_in.data_ptr(), md_out.data_ptr(), mst))
+        check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)  # all `mb` products, after the timed pass
+        folded = None
+        if not args.no_folded:
+            finfo = ia.circuit_info(4, 32, fold=True)
+            ctx.set_option("fold_constants", 1)
+            fst = ia.Stats()
+            f_elapsed, _ = timed(torch, dist, world, dev, args.backend,
+                                 lambda: ctx.eval_batch_device(4, 32, mb, md_in.data_ptr(), md_out.data_ptr(), fst))
+            ctx.set_option("fold_constants", 0)
+            check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)
+            folded = {"flag": "fold_constants=1 (IEACHE_FOLD=1): constant operands folded, repeated gates shared; decrypt-identical, "
+                              "NOT the reference's ciphertext bits; never the default",
+                      "executed_bootstraps_per_expr": int(finfo.bootstraps), "reference_bootstraps_per_expr": int(finfo.reference_bootstraps),
+                      "levels": int(finfo.depth), "ms_per_pass": f_elapsed * 1e3,
+                      "mul32_per_s": mb * world / f_elapsed,
+                      "executed_gate_ops_per_s": int(finfo.bootstraps) * mb * world / f_elapsed,
+                      "reference_equivalent_gate_ops_per_s": int(finfo.reference_bootstraps) * mb * world / f_elapsed,
+                      "speedup_vs_reference_circuit": m_elapsed / f_elapsed, "checked": "all %d products decrypt to a*b" % mb}
+        if rank == 0:
+            m_rate = int(minfo.bootstraps) * mb * world / m_elapsed
+            mul_leg = {"workload": WORKLOADS["mul32"][3], "batch_per_gpu": mb, "bootstraps_per_expr": int(minfo.bootstraps),
+                       "levels": int(minfo.depth), "passes": 1, "ms_per_pass": m_elapsed * 1e3,
+                       "gate_ops_per_s": m_rate, "mul32_per_s": mb * world / m_elapsed,
+                       "per_rank_gate_ops_per_s": [int(minfo.bootstraps) * mb / t for t in m_per_rank],
+                       "checked": "all %d products of the timed pass decrypt to a*b" % mb,
+                       "roofline": roofline(p, mst, m_rate / world, pmc), "folded": folded}
+        del md_in, md_out
 
     if rank == 0:
         gates_total = info.bootstraps * batch * args.steps * world
         value = gates_total / elapsed
-        per_gate = algorithmic_bytes_per_gate(p)
-        # dominant kernel: blind rotation (k_blind_rotate_*).  One launch advances `gates_per_launch`
-        # gates by `steps_per_launch` of their n CMux steps, i.e. processes that fraction of each gate's
-        # algorithmic bytes; achieved = algorithmic bytes per launch / average launch duration (HIP
-        # events on the evaluator's stream bracket the launches of each chunk).
-        br_avg_ms = stats.blind_rotate_ms / max(1, stats.blind_rotate_launches)
-        gates_per_launch = stats.bootstraps / max(1, stats.chunks)
-        launches_per_gate = stats.blind_rotate_launches / max(1, stats.chunks)
-        bytes_per_launch = per_gate * gates_per_launch / max(1.0, launches_per_gate)
-        achieved = bytes_per_launch / (br_avg_ms * 1e-3) / 1e9 if br_avg_ms > 0 else 0.0
-        # HBM traffic of the dominant kernel from PMC counters: collected offline (rocprofv3 cannot run
-        # inside this process) by scripts/pmc_passes.sh and committed in profiles/traffic.json
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(ctx.kernel_variant)
-            if tj:
-                traffic = tj["hbm_bytes_per_gate_step"] * gates_per_launch * (p.n / max(1.0, launches_per_gate))
-        except (OSError, ValueError, KeyError):
-            traffic = None
         out = {
-            "metric": "bootstrapped gate ops/sec",
+            "metric": "bootstrapped gate ops/sec; encrypted 32-bit MUL/sec",
             "value": value,
             "unit": "gate ops/s",
             "n_gpus": world,
@@ -217,23 +346,18 @@ def main():
             "config": {"workload": config_name, "circuit": "%s%d" % (args.workload.rstrip("0123456789"), bits),
                        "batch_per_gpu": batch, "bootstraps_per_expr": int(info.bootstraps), "levels": int(info.depth),
                        "params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2",
-                       "arithmetic": "Torus32 = int32 with wraparound; the negacyclic products inside the external product run as an exact two-limb f64 transform", "parallelism": "batch-sharded x%d" % world,
-                       "kernel": ctx.kernel_variant, "key_broadcast_s": round(t_bcast, 4)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_blind_rotate", "avg_launch_ms": br_avg_ms, "gates_per_launch": gates_per_launch,
-                         "cmux_steps_per_launch": p.n / max(1.0, launches_per_gate),
-                         "algorithmic_bytes_per_gate": per_gate, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "blind_rotate_share": stats.blind_rotate_ms / max(1e-9, stats.total_ms),
-                         "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms),
-                         # secondary line: BK is shared by all gates in flight, so the kernel's real bound is
-                         # the FP64 vector pipe: ~3 900 FP64-rate instructions per lane and CMux step
-                         "secondary": {"bound": "fp64_valu", "unit": "TFLOP/s-equivalent (1 instr = 2 flop)",
-                                       "achieved": FP64_OPS_PER_GATE * 2e-12 * (achieved * 1e9 / per_gate),
-                                       "peak": FP64_VALU_PEAK_TFLOPS,
-                                       "frac": FP64_OPS_PER_GATE * 2e-12 * (achieved * 1e9 / per_gate) / FP64_VALU_PEAK_TFLOPS}},
+                       "arithmetic": "Torus32 = int32 with wraparound; the negacyclic products inside the external product run as an exact two-limb f64 transform",
+                       "parallelism": "batch-sharded x%d" % world, "kernel": ctx.kernel_variant,
+                       "key_broadcast_s": round(t_bcast, 4),
+                       "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+                       "collective_backend": args.backend if world > 1 else None,
+                       "per_rank_gate_ops_per_s": [info.bootstraps * batch * args.steps / t for t in per_rank]},
+            "roofline": roofline(p, stats, value / world, pmc),
         }
-        if kind == 4 and bits == 32:
+        if mul_leg:
+            out["mul32"] = mul_leg
+            out["mul32_per_s"] = mul_leg["mul32_per_s"]
+        elif kind == 4 and bits == 32:
             out["mul32_per_s"] = batch * args.steps * world / elapsed
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, keys, args.cpu_seconds)

@@ -20,7 +20,11 @@ size_t state_bytes_per_item(const Params& p);
 // ext rows of N+4 int32 (may be null), dbg_acc [items][2][N] (may be null; when set, pass ext = null).
 // Returns the number of k_blind_rotate_w2 launches issued.
 int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const dev::WorkDesc& W, int64_t items,
-           void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant, hipStream_t stream);
+           void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
+           const double2* d_twiddles, hipStream_t stream);
+// the kernels' twiddle table (twiddle_table_elems() double2 in device memory), built once per context
+size_t twiddle_table_elems();
+void build_twiddle_table(double2* d_tw, hipStream_t stream);
 // kernel variant: 0 = LDS transposes, wave-local sync (default; IEACHE_BR_VARIANT overrides); 1 = same with
 // s_memtime diagnostics printed to stderr; 2 = LDS transposes with workgroup barriers; 3 = cross-lane
 // (DPP / v_permlane*_swap) transposes; 4 = 3 with diagnostics.  All produce identical bits.

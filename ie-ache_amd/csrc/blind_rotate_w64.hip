@@ -24,6 +24,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
+#include <type_traits>
 
 namespace ieache {
 namespace w64 {
@@ -122,6 +124,14 @@ __device__ __forceinline__ void build_twiddles(double2* tw, int tid, int nthread
         sincospi(-(double)(p0 * k) / 32.0, &s, &c);
         tw[512 + idx] = make_double2(c, s);
     }
+}
+
+// The table is built once per context (k_build_twiddle_table) and copied into LDS at kernel start:
+// computing it per workgroup (4.5 sincospi per thread) cost ~4 % of a 16-step slice's vector work.
+__global__ __launch_bounds__(128) void k_build_twiddle_table(double2* tw) { build_twiddles(tw, threadIdx.x, 128); }
+
+__device__ __forceinline__ void load_twiddles(double2* sTw, const double2* __restrict__ gtw, int tid, int nthreads) {
+    for (int idx = tid; idx < kTwElems; idx += nthreads) sTw[idx] = gtw[idx];
 }
 
 __device__ __forceinline__ LaneRoots make_roots(const double2* tw, int lane) {
@@ -443,7 +453,7 @@ template <int L, int BGBIT, bool DIAG, bool WSYNC, int XLANE = 0>
 __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf,
                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
                                                            int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
-                                                           unsigned long long* diag) {
+                                                           unsigned long long* diag, const double2* __restrict__ gtw) {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* sT_all = reinterpret_cast<double2*>(smem);
     double2* sTw = sT_all + 2 * kTile;
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
     const int64_t item = (int64_t)blockIdx.x;
     const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
     int32_t* gacc = st_acc + (size_t)item * 2 * kN;
-    build_twiddles(sTw, tid, 128);
+    load_twiddles(sTw, gtw, tid, 128);
     const LaneRoots R = make_roots(sTw, lane);
     {
         const int4* src = reinterpret_cast<const int4*>(gacc);
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
     }
     __syncthreads();
 
-    constexpr uint32_t halfBg = 1u << (BGBIT - 1), maskBg = (1u << BGBIT) - 1;
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
@@ -488,30 +498,28 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
         if (a == 0) continue;  // workgroup-uniform; exact arithmetic makes the step a no-op
         // BK_i rows [2L][4][8][64]; this wave reads outputs o = 2*wave, 2*wave+1 of every row
         const double2* __restrict__ bki = bkf + (size_t)i * (2 * L * 4 * kM) + (size_t)(2 * wave) * kM + lane;
-        double2 s[2][8];
-#pragma unroll
-        for (int o = 0; o < 2; o++)
-#pragma unroll
-            for (int k = 0; k < 8; k++) s[o][k] = make_double2(0.0, 0.0);
+        double2 s[2][8];  // written (not accumulated into) by digit 0's own-row products below
         // (X^a - 1) * acc_w at this lane's 16 coefficients, plus the decomposition offset
         uint32_t v0[8], v1[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int32_t j = 64 * r + lane;
-            v0[r] = (uint32_t)rot_coef(accw, j, a, kN) - (uint32_t)accw[j] + dec_offset;
-            v1[r] = (uint32_t)rot_coef(accw, j + kM, a, kN) - (uint32_t)accw[j + kM] + dec_offset;
+            // (x + C) ^ C with C = sum_q halfBg << shift_q: digit q's field then holds digit ^ halfBg, whose
+            // sign-extended BGBIT-bit value IS digit - halfBg (one v_bfe_i32 per digit below)
+            v0[r] = (((uint32_t)rot_coef(accw, j, a, kN) - (uint32_t)accw[j]) + dec_offset) ^ dec_offset;
+            v1[r] = (((uint32_t)rot_coef(accw, j + kM, a, kN) - (uint32_t)accw[j + kM]) + dec_offset) ^ dec_offset;
         }
         IEACHE_STAMP(0)
-#pragma unroll 1
-        for (int q = 0; q < L; q++) {
+        auto digit_row = [&](const int q, auto first) {
+            constexpr bool FIRST = decltype(first)::value;  // digit 0: its own-row products initialise s
             const int sh = 32 - (q + 1) * BGBIT;
             const double2* __restrict__ bown = bki + (size_t)(wave * L + q) * (4 * kM);
             const double2* __restrict__ bpar = bki + (size_t)((wave ^ 1) * L + q) * (4 * kM);
             double2 x[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const int32_t e0 = (int32_t)((v0[r] >> sh) & maskBg) - (int32_t)halfBg;
-                const int32_t e1 = (int32_t)((v1[r] >> sh) & maskBg) - (int32_t)halfBg;
+                const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
+                const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
                 x[r] = r == 0 ? make_double2((double)e0, (double)e1)  // exp(0) = 1: nothing to multiply
                             : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
@@ -536,16 +544,18 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                s[0][k] = make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[0][k].x)),
-                                       fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[0][k].y)));
+                s[0][k] = FIRST ? cmulx<false>(x[k], bA[k])
+                                : make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[0][k].x)),
+                                               fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[0][k].y)));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; k++) bA[k] = bpar[(8 + k) * 64];  // bD
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                s[1][k] = make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
-                                       fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
+                s[1][k] = FIRST ? cmulx<false>(x[k], bB[k])
+                                : make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
+                                               fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
             IEACHE_STAMP(2)
             __syncthreads();
             IEACHE_STAMP(3)
@@ -563,7 +573,10 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
             IEACHE_STAMP(4)
             __syncthreads();  // partner has read our tile before the next transform reuses it
             IEACHE_STAMP(5)
-        }
+        };
+        digit_row(0, std::true_type{});
+#pragma unroll 1
+        for (int q = 1; q < L; q++) digit_row(q, std::false_type{});
         // back to coefficients, round, recombine the two limbs, accumulate into polynomial `wave`
         if (XLANE == 0) {
             fft512_inverse_pair<WSYNC>(s[0], s[1], sT, lane, R);
@@ -620,7 +633,7 @@ template <int L, int BGBIT, bool DIAG>
 __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const double2* __restrict__ bkf,
                                                              const uint16_t* __restrict__ st_bara, int32_t nb,
                                                              int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
-                                                             unsigned long long* diag) {
+                                                             unsigned long long* diag, const double2* __restrict__ gtw) {
     constexpr int NW = 2 * L, NT = 64 * NW;
     extern __shared__ __align__(16) unsigned char smem[];
     double2* sT_all = reinterpret_cast<double2*>(smem);
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
     double2* sT = sT_all + wave * kTile;
     const int64_t item = (int64_t)blockIdx.x;
     int32_t* gacc = st_acc + (size_t)item * 2 * kN;
-    build_twiddles(sTw, tid, NT);
+    load_twiddles(sTw, gtw, tid, NT);
     const LaneRoots R = make_roots(sTw, lane);
     {
         const int4* src = reinterpret_cast<const int4*>(gacc);
@@ -643,7 +656,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
     }
     __syncthreads();
 
-    constexpr uint32_t halfBg = 1u << (BGBIT - 1), maskBg = (1u << BGBIT) - 1;
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
@@ -704,8 +717,9 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
             const uint32_t n1 = 0u - (((uint32_t)(jb + 64 * r + kM) >> 10) & 1u);
             const uint32_t u0 = ((rv0[r] ^ n0) - n0) - pv0[r] + dec_offset;
             const uint32_t u1 = ((rv1[r] ^ n1) - n1) - pv1[r] + dec_offset;
-            const int32_t e0 = (int32_t)((u0 >> sh) & maskBg) - (int32_t)halfBg;
-            const int32_t e1 = (int32_t)((u1 >> sh) & maskBg) - (int32_t)halfBg;
+            // digit - halfBg = sign-extended field of (u ^ (halfBg << sh))
+            const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)(u0 ^ (halfBg << sh)), sh, BGBIT);
+            const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
             x[r] = r == 0 ? make_double2((double)e0, (double)e1)
                           : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
         }
@@ -812,6 +826,12 @@ size_t lds_bytes_wide(const Params& p) {
 
 size_t state_bytes_per_item(const Params& p) { return (size_t)bara_stride(p) * 2 + (size_t)2 * kN * 4; }
 
+size_t twiddle_table_elems() { return kTwElems; }
+
+void build_twiddle_table(double2* d_tw, hipStream_t stream) {
+    hipLaunchKernelGGL(k_build_twiddle_table, dim3(1), dim3(128), 0, stream, d_tw);
+}
+
 void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, hipStream_t stream) {
     const size_t npoly = (size_t)p.n * p.kpl() * 2;
     hipLaunchKernelGGL(k_bk_to_spectrum_w64, dim3((unsigned)npoly), dim3(64), 0, stream, d_bk_raw, d_bkf);
@@ -821,8 +841,11 @@ void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, 
 static unsigned long long* diag_buf() {
     static unsigned long long* p = nullptr;
     if (!p) {
-        (void)hipMalloc(&p, 16 * sizeof(unsigned long long));
-        (void)hipMemset(p, 0, 16 * sizeof(unsigned long long));
+        if (hipMalloc(&p, 16 * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(p, 0, 16 * sizeof(unsigned long long)) != hipSuccess) {
+            p = nullptr;
+            throw std::runtime_error("hipMalloc failed for the blind-rotation diagnostic buffer");
+        }
     }
     return p;
 }
@@ -848,7 +871,8 @@ static void diag_report(hipStream_t stream, int64_t items, int32_t nsteps, int v
 
 template <int L, int BGBIT>
 static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream_t stream, const DevKeys& K, const double2* d_bkf,
-                         const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e) {
+                         const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e,
+                         const double2* gtw) {
     unsigned long long* const nodiag = nullptr;
     if (variant == kVariantWide || variant == kVariantWide + 1) {
         static const bool attr_set = [] {  // > 64 KiB of dynamic LDS has to be allowed explicitly
@@ -857,22 +881,22 @@ static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream
                    hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024) == hipSuccess;
         }();
-        (void)attr_set;
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide");
         const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
         if (variant == kVariantWide)
-            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag);
+            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw);
         else
-            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, true>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf());
+            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, true>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw);
         return;
     }
     switch (variant) {
-        case 1: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
-        case 2: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
-        case 3: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
-        case 4: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf()); break;
-        case 5: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
-        case 6: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 2>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
-        default: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag); break;
+        case 1: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw); break;
+        case 2: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
+        case 3: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
+        case 4: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw); break;
+        case 5: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
+        case 6: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 2>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
+        default: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
     }
 }
 
@@ -887,7 +911,8 @@ int32_t default_slice() {
 }
 
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDesc& W, int64_t items, void* state,
-           Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant, hipStream_t stream) {
+           Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant, const double2* d_twiddles,
+           hipStream_t stream) {
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
     const size_t lds = lds_bytes(p);
@@ -905,17 +930,17 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
         Torus32* e = (i1 == nsteps) ? ext : nullptr;  // the last slice extracts instead of storing the accumulator
         launches++;
         if (p.l == 3)
-            launch_slice<3, 7>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e);
+            launch_slice<3, 7>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, d_twiddles);
         else
-            launch_slice<2, 10>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e);
+            launch_slice<2, 10>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, d_twiddles);
     }
     if (variant == 1 || variant == 4 || variant == kVariantWide + 1) diag_report(stream, items, nsteps, variant);
     if (nsteps == 0 && ext) {
         // degenerate (steps == 0): extraction straight from the initial accumulator
         if (p.l == 3)
-            launch_slice<3, 7>(0, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext);
+            launch_slice<3, 7>(0, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext, d_twiddles);
         else
-            launch_slice<2, 10>(0, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext);
+            launch_slice<2, 10>(0, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext, d_twiddles);
     }
     if (dbg_acc)
         (void)hipMemcpyAsync(dbg_acc, st_acc, (size_t)items * 2 * kN * 4, hipMemcpyDeviceToDevice, stream);

@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "circuit.h"
@@ -23,8 +24,9 @@ using namespace ieache;
 
 struct ieache_ctx {
     std::unique_ptr<Evaluator> eval;
-    std::map<std::pair<int, int>, Circuit> circuits;
+    std::map<std::tuple<int, int, bool>, Circuit> circuits;
     std::string variant;
+    bool fold = false;  // "fold_constants"
 };
 
 namespace {
@@ -91,17 +93,34 @@ void to_stats(const EvalStats& s, ieache_stats* o) {
     o->chunks = s.chunks;
 }
 const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits) {
-    auto key = std::make_pair(kind, bits);
+    auto key = std::make_tuple(kind, bits, ctx->fold);
     auto it = ctx->circuits.find(key);
     if (it != ctx->circuits.end()) return &it->second;
     Circuit c;
-    if (!build_circuit(kind, bits, &c)) return nullptr;
+    if (!build_circuit(kind, bits, &c, true, ctx->fold)) return nullptr;
     return &ctx->circuits.emplace(key, std::move(c)).first->second;
 }
-ieache_ctx* make_ctx(const Params& p, int device) {
-    auto* ctx = new ieache_ctx;
+// the context is owned by a unique_ptr until it is handed to the caller, so a throwing key load
+// (or Evaluator constructor) releases it
+template <class Load>
+ieache_ctx* make_ctx(const Params& p, int device, Load&& load) {
+    std::unique_ptr<ieache_ctx> ctx(new ieache_ctx);
     ctx->eval.reset(new Evaluator(p, device));
-    return ctx;
+    load(*ctx->eval);
+    return ctx.release();
+}
+void fill_info(const Circuit& c, bool fold, ieache_circuit_info* out) {
+    out->n_inputs = c.n_inputs;
+    out->n_outputs = (int32_t)c.outputs.size();
+    out->n_slots = c.n_slots;
+    out->depth = c.depth;
+    out->max_width = c.max_width;
+    out->bootstraps = c.n_bootstraps;
+    out->n_and = c.n_and;
+    out->n_xor = c.n_xor;
+    out->sched_max_width = c.sched_max_width;
+    out->folded = fold ? 1 : 0;
+    out->reference_bootstraps = c.n_reference_bootstraps;
 }
 }  // namespace
 
@@ -109,6 +128,7 @@ extern "C" {
 
 const char* ieache_version(void) { return "ieache-amd 0.1 (gfx950)"; }
 const char* ieache_last_error(void) { return g_err.c_str(); }
+const char* ieache_last_key_layout(void) { return last_key_layout().c_str(); }
 
 int ieache_device_count(void) {
     int n = 0;
@@ -132,45 +152,30 @@ ieache_ctx* ieache_ctx_create(const char* cloud_key_path, int device) {
         if (!cloud_key_path) return fail(IEACHE_EINVAL, "null path");
         CloudKeyData ck;
         load_cloud_key(cloud_key_path, &ck);
-        ctx = make_ctx(ck.p, device);
-        ctx->eval->load_keys_host(ck.bk.data(), ck.ksk.data());
+        ctx = make_ctx(ck.p, device, [&](Evaluator& e) { e.load_keys_host(ck.bk.data(), ck.ksk.data()); });
         return 0;
     });
-    if (rc != 0) {
-        delete ctx;
-        return nullptr;
-    }
-    return ctx;
+    return rc == 0 ? ctx : nullptr;
 }
 
 ieache_ctx* ieache_ctx_create_raw(const ieache_params* p, const int32_t* bk, const int32_t* ksk, int device) {
     ieache_ctx* ctx = nullptr;
     const int rc = guarded([&] {
         if (!p || !bk || !ksk) return fail(IEACHE_EINVAL, "null argument");
-        ctx = make_ctx(to_params(*p), device);
-        ctx->eval->load_keys_host(bk, ksk);
+        ctx = make_ctx(to_params(*p), device, [&](Evaluator& e) { e.load_keys_host(bk, ksk); });
         return 0;
     });
-    if (rc != 0) {
-        delete ctx;
-        return nullptr;
-    }
-    return ctx;
+    return rc == 0 ? ctx : nullptr;
 }
 
 ieache_ctx* ieache_ctx_create_device(const ieache_params* p, const int32_t* d_bk, const int32_t* d_ksk, int device) {
     ieache_ctx* ctx = nullptr;
     const int rc = guarded([&] {
         if (!p || !d_bk || !d_ksk) return fail(IEACHE_EINVAL, "null argument");
-        ctx = make_ctx(to_params(*p), device);
-        ctx->eval->load_keys_device(d_bk, d_ksk);
+        ctx = make_ctx(to_params(*p), device, [&](Evaluator& e) { e.load_keys_device(d_bk, d_ksk); });
         return 0;
     });
-    if (rc != 0) {
-        delete ctx;
-        return nullptr;
-    }
-    return ctx;
+    return rc == 0 ? ctx : nullptr;
 }
 
 void ieache_ctx_destroy(ieache_ctx* ctx) {
@@ -207,8 +212,21 @@ int ieache_ctx_force_generic(ieache_ctx* ctx, int on) {
     return 0;
 }
 
+int ieache_ctx_wait_stream(ieache_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(IEACHE_EINVAL, "null context");
+    return guarded([&] {
+        ctx->eval->wait_for_stream((hipStream_t)hip_stream);
+        return 0;
+    });
+}
+
 int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(IEACHE_EINVAL, "null argument");
+    if (std::string(name) == "fold_constants") {
+        if (value != 0 && value != 1) return fail(IEACHE_EINVAL, "fold_constants takes 0 or 1");
+        ctx->fold = value != 0;
+        return 0;
+    }
     if (!ctx->eval->set_option(name, value)) return fail(IEACHE_EINVAL, std::string("unknown option or bad value: ") + name);
     return 0;
 }
@@ -219,33 +237,28 @@ const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx) {
     return ctx->variant.c_str();
 }
 
-int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out) {
+int ieache_circuit_info_get_ex(int kind, int bits, int fold_constants, ieache_circuit_info* out) {
     return guarded([&] {
         if (!out) return fail(IEACHE_EINVAL, "null argument");
         Circuit c;
-        if (!build_circuit(kind, bits, &c)) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
-        out->n_inputs = c.n_inputs;
-        out->n_outputs = (int32_t)c.outputs.size();
-        out->n_slots = c.n_slots;
-        out->depth = c.depth;
-        out->max_width = c.max_width;
-        out->bootstraps = c.n_bootstraps;
-        out->n_and = c.n_and;
-        out->n_xor = c.n_xor;
-        out->sched_max_width = c.sched_max_width;
-        out->reserved = 0;
+        if (!build_circuit(kind, bits, &c, true, fold_constants != 0)) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
+        fill_info(c, fold_constants != 0, out);
         return 0;
     });
 }
+int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out) { return ieache_circuit_info_get_ex(kind, bits, 0, out); }
 
-int ieache_circuit_simulate(int kind, int bits, const uint8_t* in_bits, uint8_t* out_bits) {
+int ieache_circuit_simulate_ex(int kind, int bits, int fold_constants, const uint8_t* in_bits, uint8_t* out_bits) {
     return guarded([&] {
         if (!in_bits || !out_bits) return fail(IEACHE_EINVAL, "null argument");
         Circuit c;
-        if (!build_circuit(kind, bits, &c)) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
+        if (!build_circuit(kind, bits, &c, true, fold_constants != 0)) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
         simulate_circuit(c, in_bits, out_bits);
         return 0;
     });
+}
+int ieache_circuit_simulate(int kind, int bits, const uint8_t* in_bits, uint8_t* out_bits) {
+    return ieache_circuit_simulate_ex(kind, bits, 0, in_bits, out_bits);
 }
 
 int ieache_eval_batch(ieache_ctx* ctx, int kind, int bits, size_t batch, const int32_t* in_lwe, int32_t* out_lwe,
@@ -323,6 +336,35 @@ int ieache_gates(ieache_ctx* ctx, int gate_type, size_t count, const int32_t* a,
     });
 }
 
+int ieache_mux_device(ieache_ctx* ctx, size_t count, const int32_t* d_a, const int32_t* d_b, const int32_t* d_c,
+                      int32_t* d_out, ieache_stats* stats) {
+    return guarded([&] {
+        if (!ctx || !d_a || !d_b || !d_c || !d_out) return fail(IEACHE_EINVAL, "null argument");
+        EvalStats st;
+        ctx->eval->mux_device(count, d_a, d_b, d_c, d_out, stats ? &st : nullptr);
+        to_stats(st, stats);
+        return 0;
+    });
+}
+
+int ieache_mux(ieache_ctx* ctx, size_t count, const int32_t* a, const int32_t* b, const int32_t* c, int32_t* out,
+               ieache_stats* stats) {
+    return guarded([&] {
+        if (!ctx || !a || !b || !c || !out) return fail(IEACHE_EINVAL, "null argument");
+        const Params& p = ctx->eval->params();
+        HIP_CHECK(hipSetDevice(ctx->eval->device()));
+        DevRows da(count, p.lwe_stride()), db(count, p.lwe_stride()), dc(count, p.lwe_stride()), dout(count, p.lwe_stride());
+        da.upload(a, p.n + 1);
+        db.upload(b, p.n + 1);
+        dc.upload(c, p.n + 1);
+        EvalStats st;
+        ctx->eval->mux_device(count, da.p, db.p, dc.p, dout.p, stats ? &st : nullptr);
+        dout.download(out, p.n + 1);
+        to_stats(st, stats);
+        return 0;
+    });
+}
+
 int ieache_debug_blind_rotate(ieache_ctx* ctx, size_t count, const int32_t* x, int32_t* acc, int32_t steps) {
     return guarded([&] {
         if (!ctx || !x || !acc) return fail(IEACHE_EINVAL, "null argument");
@@ -374,11 +416,11 @@ int ieache_keygen_files(const char* dir, const ieache_params* p, const uint32_t*
         if (p) pp = to_params(*p);
         if (!pp.supported()) return fail(IEACHE_EINVAL, "unsupported parameter set");
         static const uint32_t kSeed[3] = {314, 1592, 657}, kBitSeed[3] = {314, 1592, 888};  // keygen.c:30,34
-        if (!seed) {
+        if (!seed && n_seed >= 0) {
             seed = kSeed;
             n_seed = 3;
         }
-        if (!nbit_seed) {
+        if (!nbit_seed && n_nbit_seed >= 0) {
             nbit_seed = kBitSeed;
             n_nbit_seed = 3;
         }
@@ -397,7 +439,7 @@ int ieache_encrypt_bits(const ieache_params* p, const int32_t* lwe_key, const ui
     return guarded([&] {
         if (!p || !lwe_key || !bits || !out) return fail(IEACHE_EINVAL, "null argument");
         const Params pp = to_params(*p);
-        Rng rng(seed);
+        Rng rng = seed ? Rng(seed) : Rng::secure();
         for (size_t i = 0; i < count; i++) lwe_encrypt_bit(pp, lwe_key, bits[i] & 1, rng, out + i * (size_t)(pp.n + 1));
         return 0;
     });
@@ -429,16 +471,7 @@ int ieache_read_cloud_key(const char* path, ieache_params* p, int32_t* bk, int32
     return guarded([&] {
         if (!path) return fail(IEACHE_EINVAL, "null path");
         if (!bk && !ksk) {
-            FILE* f = fopen(path, "rb");
-            if (!f) throw CodecError(std::string("cannot open ") + path);
-            Params pp;
-            try {
-                pp = read_params(f);
-            } catch (...) {
-                fclose(f);
-                throw;
-            }
-            fclose(f);
+            const Params pp = load_params(path);
             if (p) from_params(pp, p);
             return 0;
         }
@@ -522,7 +555,7 @@ int ieache_alice(const char* secret_key_path, const char* nbit_key_path, const c
         if (key.p.n != nbit.p.n) throw CodecError("secret.key and nbit.key disagree on n");
         const size_t S = (size_t)key.p.n + 1;
         std::vector<Torus32> rows(352 * S);
-        Rng rng(seed);
+        Rng rng = seed ? Rng(seed) : Rng::secure();
         auto enc_word = [&](const SecretKeyData& k, uint32_t v, size_t word_index) {
             for (int i = 0; i < 32; i++)  // alice.c:123-125: bit i of the word is sample i
                 lwe_encrypt_bit(k.p, k.lwe_key.data(), (v >> i) & 1, rng, rows.data() + (word_index * 32 + i) * S);

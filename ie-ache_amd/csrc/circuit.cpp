@@ -9,8 +9,8 @@
 
 namespace ieache {
 
-CircuitBuilder::CircuitBuilder(int32_t n_inputs)
-    : n_inputs_(n_inputs), next_wire_(n_inputs), wire_level_(n_inputs, 0) {}
+CircuitBuilder::CircuitBuilder(int32_t n_inputs, bool fold)
+    : n_inputs_(n_inputs), next_wire_(n_inputs), fold_(fold), wire_level_(n_inputs, 0) {}
 
 Ref CircuitBuilder::input(int32_t i) const {
     if (i < 0 || i >= n_inputs_) throw std::out_of_range("circuit input index");
@@ -26,6 +26,27 @@ Word CircuitBuilder::input_word(int32_t first, int32_t count) const {
 Ref CircuitBuilder::gate(int32_t type, Ref a, Ref b) {
     if (a.id == kUndefId || b.id == kUndefId)
         throw std::logic_error("gate consumes a never-written sample");
+    n_requested_++;
+    bool out_neg = false;
+    if (fold_ && (type == GATE_AND || type == GATE_XOR)) {
+        const bool ca = a.id == kConstId, cb = b.id == kConstId;
+        if (type == GATE_AND) {
+            if (ca) return a.neg ? b : constant(0);  // 1 AND b = b ; 0 AND b = 0
+            if (cb) return b.neg ? a : constant(0);
+            if (a.id == b.id) return a.neg == b.neg ? a : constant(0);  // x AND x ; x AND NOT x
+        } else {
+            if (ca) return Ref{b.id, b.neg != a.neg};  // 0 XOR b = b ; 1 XOR b = NOT b
+            if (cb) return Ref{a.id, a.neg != b.neg};
+            if (a.id == b.id) return constant(a.neg != b.neg);
+            out_neg = a.neg != b.neg;  // XOR(NOT a, b) = NOT XOR(a, b): negations move to the output
+            a.neg = b.neg = false;
+        }
+        if (a.id > b.id) std::swap(a, b);  // both gates commute
+        const auto key = std::make_tuple(type, a.id, (int32_t)a.neg, b.id, (int32_t)b.neg);
+        const auto it = known_.find(key);
+        if (it != known_.end()) return Ref{it->second, out_neg};
+        known_[key] = next_wire_;
+    }
     const int32_t la = a.id >= 0 ? wire_level_[a.id] : 0;
     const int32_t lb = b.id >= 0 ? wire_level_[b.id] : 0;
     Gate g;
@@ -36,7 +57,7 @@ Ref CircuitBuilder::gate(int32_t type, Ref a, Ref b) {
     g.level = std::max(la, lb) + 1;
     wire_level_.push_back(g.level);
     gates_.push_back(g);
-    return Ref{g.out, false};
+    return Ref{g.out, out_neg};
 }
 
 // cloud.c:18-51.  carry-in is c[0] (bootsCOPY :24); carry-out lands in
@@ -266,7 +287,23 @@ Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const
     return c;
 }
 
+bool decode_chain(int32_t kind, int32_t* k1, int32_t* k2, bool* flip) {
+    if (kind == CIRC_MULADD) kind = chain_kind(CIRC_MUL, CIRC_ADD, true);
+    if (kind < CIRC_CHAIN_BASE || kind >= CIRC_CHAIN_END) return false;
+    const int32_t c = kind - CIRC_CHAIN_BASE;
+    *k1 = (c & 3) + 1;
+    *k2 = ((c >> 2) & 3) + 1;
+    *flip = (c & 16) == 0;
+    return true;
+}
+
 int32_t circuit_n_inputs(int32_t kind, int32_t bits) {
+    int32_t k1, k2;
+    bool flip;
+    if (decode_chain(kind, &k1, &k2, &flip)) {
+        const int32_t w2 = k1 == CIRC_MUL ? 2 * bits : bits;
+        return 2 * bits + 32 + w2 + (flip ? 0 : 32);
+    }
     switch (kind) {
         case CIRC_ADD:
         case CIRC_SUB:
@@ -276,13 +313,17 @@ int32_t circuit_n_inputs(int32_t kind, int32_t bits) {
         case CIRC_SUB_KS:
         case CIRC_RSUB_KS:
             return 2 * bits + 32;
-        case CIRC_MULADD:
-            return 2 * bits + 32 + 2 * bits;
     }
     return -1;
 }
 
 int32_t circuit_n_outputs(int32_t kind, int32_t bits) {
+    int32_t k1, k2;
+    bool flip;
+    if (decode_chain(kind, &k1, &k2, &flip)) {
+        const int32_t w2 = k1 == CIRC_MUL ? 2 * bits : bits;
+        return k2 == CIRC_MUL ? 2 * w2 : w2;
+    }
     switch (kind) {
         case CIRC_ADD:
         case CIRC_SUB:
@@ -292,7 +333,6 @@ int32_t circuit_n_outputs(int32_t kind, int32_t bits) {
         case CIRC_RSUB_KS:
             return bits;
         case CIRC_MUL:
-        case CIRC_MULADD:
             return 2 * bits;
     }
     return -1;
@@ -371,50 +411,32 @@ static Word kogge_stone_add(CircuitBuilder& b, const Word& x, const Word& y, Ref
     return sum;
 }
 
-bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced) {
-    if (bits < 1 || bits > 256) return false;
-    const int32_t n_in = circuit_n_inputs(kind, bits);
-    if (n_in < 0) return false;
-    CircuitBuilder b(n_in);
-    Word A = b.input_word(0, bits), B = b.input_word(bits, bits);
-    const Word carry1 = b.input_word(2 * bits, 32);  // ciphertextcarry1
+// One branch of main() (cloud.c:870-2718) on symbolic operands: `bits`-wide A and B (a multiple
+// of 32 except for the generalised adders), carry = ciphertextcarry1.  Returns the value samples
+// LSB first, or an empty word for an unsupported (kind, bits).
+static Word build_stage(CircuitBuilder& b, int32_t kind, int32_t bits, const Word& A, const Word& B, const Word& carry1) {
     const std::vector<Word> Aw = to_words(A), Bw = to_words(B);
     Word result;
-    std::string name;
     switch (kind) {
         case CIRC_ADD:
-            result = chained_add(b, Aw, Bw, carry1);
-            name = "add";
-            break;
+            return chained_add(b, Aw, Bw, carry1);
         case CIRC_SUB:  // cloud.c:1196-1807: complement operand 2, add to operand 1
-            result = chained_add(b, Aw, twos_complement(b, Bw), carry1);
-            name = "sub";
-            break;
+            return chained_add(b, Aw, twos_complement(b, Bw), carry1);
         case CIRC_RSUB:  // cloud.c:1809-2365: complement operand 1, add to operand 2
-            result = chained_add(b, Bw, twos_complement(b, Aw), carry1);
-            name = "rsub";
-            break;
+            return chained_add(b, Bw, twos_complement(b, Aw), carry1);
         case CIRC_ADD_KS:
-            result = kogge_stone_add(b, A, B, carry1[0]);
-            name = "add_ks";
-            break;
+            return kogge_stone_add(b, A, B, carry1[0]);
         case CIRC_SUB_KS: {  // A + ~B + 1 (the reference's carry word encrypts 0: alice.c:147-149)
             Word nb(bits);
             CircuitBuilder::NOT(nb, B, bits);
-            result = kogge_stone_add(b, A, nb, CircuitBuilder::constant(1));
-            name = "sub_ks";
-            break;
+            return kogge_stone_add(b, A, nb, CircuitBuilder::constant(1));
         }
         case CIRC_RSUB_KS: {
             Word na(bits);
             CircuitBuilder::NOT(na, A, bits);
-            result = kogge_stone_add(b, B, na, CircuitBuilder::constant(1));
-            name = "rsub_ks";
-            break;
+            return kogge_stone_add(b, B, na, CircuitBuilder::constant(1));
         }
         case CIRC_MUL:
-        case CIRC_MULADD: {
-            if (kind == CIRC_MULADD && bits != 64) return false;
             if (bits == 32) {  // cloud.c:2655-2718
                 Word r1 = b.fresh(), r2 = b.fresh();
                 b.mul32(r1, r2, Aw[0], Bw[0], carry1, 32);
@@ -454,34 +476,74 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced) {
                 b.add(sm[15], co[15], r[16], carry1, co[14], 32);
                 for (const Word* w : {&r[5], &sm[1], &sm[6], &sm[11], &sm[12], &sm[13], &sm[14], &sm[15]})  // :2476-2491
                     result.insert(result.end(), w->begin(), w->end());
-            } else {
-                return false;
             }
-            name = "mul";
-            if (kind == CIRC_MULADD) {
-                // Second ./cloud run of compute_final() (dragonfly_cipher_cloud.py:1300-1327,
-                // flip == True: [answer | operand C]).  The stage-1 answer advertises
-                // 2*bits, so stage 2 is ADD at int_bit = 2*bits (cloud.c:841-855) over the
-                // answer's words and C's words, carry-in = the answer's carry word, which is
-                // operand A's carry word (cloud.c:2617-2626 fills it with ciphertextcarry1).
-                const Word C = b.input_word(2 * bits + 32, 2 * bits);
-                result = chained_add(b, to_words(result), to_words(C), carry1);
-                name = "muladd";
-            }
-            break;
-        }
-        default:
-            return false;
+            return result;
     }
+    return result;
+}
+
+static const char* stage_name(int32_t kind) {
+    switch (kind) {
+        case CIRC_ADD: return "add";
+        case CIRC_SUB: return "sub";
+        case CIRC_RSUB: return "rsub";
+        case CIRC_MUL: return "mul";
+        case CIRC_ADD_KS: return "add_ks";
+        case CIRC_SUB_KS: return "sub_ks";
+        case CIRC_RSUB_KS: return "rsub_ks";
+    }
+    return "?";
+}
+
+bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool fold) {
+    if (bits < 1 || bits > 256) return false;
+    const int32_t n_in = circuit_n_inputs(kind, bits);
+    if (n_in < 0) return false;
+    CircuitBuilder b(n_in, fold);
+    const Word A = b.input_word(0, bits), B = b.input_word(bits, bits);
+    const Word carry1 = b.input_word(2 * bits, 32);  // ciphertextcarry1
+    Word result;
+    std::string name;
+    int32_t k1, k2;
+    bool flip;
+    bool has_mul = kind == CIRC_MUL;
+    int32_t sched_bits = bits;
+    if (decode_chain(kind, &k1, &k2, &flip)) {
+        // Two ./cloud runs of compute() / compute_final() (dragonfly_cipher_cloud.py:1219-1327) as
+        // one DAG.  Stage 1's answer advertises bits (ADD/SUB) or 2*bits (MUL: cloud.c:833-844), the
+        // third operand C is given at that width, so stage 2 runs at int_bit = w2 (cloud.c:841-855).
+        // Its carry-in is operand 1's carry word (e.g. cloud.c:891): when the answer is operand 1
+        // (flip) that is the answer's 11th word, which main() fills with stage 1's
+        // ciphertextcarry1 (cloud.c:901-916, 2617-2626); otherwise it is C's own carry word.
+        if ((k1 == CIRC_MUL || k1 > CIRC_MUL) && bits % 32) return false;
+        const int32_t w2 = k1 == CIRC_MUL ? 2 * bits : bits;
+        if (k2 == CIRC_MUL && w2 != 32 && w2 != 64 && w2 != 128) return false;  // cloud.c:860-864 refuses 256
+        if (k1 == CIRC_MUL && bits != 32 && bits != 64 && bits != 128) return false;
+        const Word stage1 = build_stage(b, k1, bits, A, B, carry1);
+        if (stage1.empty()) return false;
+        const Word C = b.input_word(2 * bits + 32, w2);
+        const Word carry2 = flip ? carry1 : b.input_word(2 * bits + 32 + w2, 32);
+        result = flip ? build_stage(b, k2, w2, stage1, C, carry2) : build_stage(b, k2, w2, C, stage1, carry2);
+        name = std::string(stage_name(k1)) + "_" + stage_name(k2) + (flip ? "" : "_r");
+        if (kind == CIRC_MULADD) name = "muladd";
+        has_mul = k1 == CIRC_MUL || k2 == CIRC_MUL;
+        if (k2 == CIRC_MUL) sched_bits = w2;  // the wider multiplier decides the schedule below
+    } else {
+        if (kind == CIRC_MUL && bits != 32 && bits != 64 && bits != 128) return false;
+        result = build_stage(b, kind, bits, A, B, carry1);
+        name = stage_name(kind);
+    }
+    if (result.empty()) return false;
     // Schedule choice.  Measured (mul32, batches 32..1024) plain ASAP is 1-3 % faster than the
     // slack-balanced schedule -- its big early levels run at full machine width -- so the balanced
     // schedule is used where it pays in memory: the 64/128-bit multipliers, whose ASAP wire store
     // is 2.7-5.8x larger (mul128: 16 800 vs 2 921 rows of 2.5 KB per expression).
     static const char* force = getenv("IEACHE_SCHEDULE");  // "asap" | "balanced": A/B switch for measurements
-    bool use_balanced = balanced && (kind == CIRC_MUL || kind == CIRC_MULADD) && bits >= 64;
+    bool use_balanced = balanced && has_mul && sched_bits >= 64;
     if (force && std::string(force) == "asap") use_balanced = false;
     if (force && std::string(force) == "balanced") use_balanced = balanced;
-    *out = finalize_circuit(name + std::to_string(bits), b, result, use_balanced);
+    *out = finalize_circuit(name + std::to_string(bits) + (fold ? "_folded" : ""), b, result, use_balanced);
+    out->n_reference_bootstraps = b.n_requested();
     return true;
 }
 

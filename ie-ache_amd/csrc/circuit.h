@@ -9,7 +9,9 @@
 // alias, constant).
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace ieache {
@@ -39,7 +41,12 @@ using Word = std::vector<Ref>;
 // Mirrors the helper functions of cloud.c on symbolic samples.
 class CircuitBuilder {
 public:
-    explicit CircuitBuilder(int32_t n_inputs);
+    // fold: constant-fold and share gates while recording (opt-in, SURVEY App. C note): a gate with
+    // a bootsCONSTANT operand, or with the same sample on both inputs, collapses to a wire / its
+    // NOT / a constant, and a gate already recorded on the same operands is reused.  The circuit
+    // then decrypts to the same bits with fewer bootstraps; its ciphertext bits differ from the
+    // reference's (which bootstraps even `x AND 0`), so this is never the default.
+    explicit CircuitBuilder(int32_t n_inputs, bool fold = false);
     Ref input(int32_t i) const;
     Word input_word(int32_t first, int32_t count = 32) const;
     static Ref constant(int v) { return Ref{kConstId, v != 0}; }            // bootsCONSTANT
@@ -69,12 +76,16 @@ public:
     int32_t n_inputs() const { return n_inputs_; }
     const std::vector<Gate>& gates() const { return gates_; }
     int32_t n_wires() const { return next_wire_; }
+    int64_t n_requested() const { return n_requested_; }  // gates the reference performs (before folding)
 
 private:
     int32_t n_inputs_;
     int32_t next_wire_;
+    bool fold_;
+    int64_t n_requested_ = 0;
     std::vector<Gate> gates_;
     std::vector<int32_t> wire_level_;
+    std::map<std::tuple<int32_t, int32_t, int32_t, int32_t, int32_t>, int32_t> known_;  // (type,a,na,b,nb) -> wire
 };
 
 // One gate as the device executor consumes it.  Slots index the wire store;
@@ -103,6 +114,7 @@ struct Circuit {
     int64_t n_bootstraps = 0, n_and = 0, n_xor = 0;
     int32_t depth = 0, max_width = 0;  // ASAP depth / widest ASAP level
     int32_t sched_max_width = 0;       // widest level of the schedule actually executed
+    int64_t n_reference_bootstraps = 0;  // what cloud.c performs for this circuit (== n_bootstraps unless folded)
     int32_t n_levels() const { return (int32_t)level_offset.size() - 1; }
 };
 
@@ -119,7 +131,7 @@ enum CircuitKind : int32_t {
     CIRC_SUB = 2,     // A + (~B+1)           cloud.c:1196-1807
     CIRC_RSUB = 3,    // B + (~A+1)           cloud.c:1809-2365
     CIRC_MUL = 4,     // A*B, double width    cloud.c:2366-2718
-    CIRC_MULADD = 5,  // (A*B)+C fused two-stage (compute_final chaining), 64-bit A,B
+    CIRC_MULADD = 5,  // (A*B)+C fused two-stage (compute_final chaining), 32/64/128-bit A,B
     // parallel-prefix (Kogge-Stone) adders, still XOR/AND only.  Same inputs and
     // outputs as ADD/SUB/RSUB and the same decrypted result (the carry word must encrypt 0, as
     // alice.c:147-149 guarantees), but NOT the same ciphertext bits: depth 2*log2(bits)+2 instead
@@ -127,14 +139,26 @@ enum CircuitKind : int32_t {
     CIRC_ADD_KS = 6,
     CIRC_SUB_KS = 7,
     CIRC_RSUB_KS = 8,
+    // any two operators chained as compute_final() does
+    // (Cloud/dragonfly_cipher_cloud.py:1300-1327), fused into one DAG: stage 1 = k1(A, B),
+    // stage 2 = k2(op1, op2) with (op1, op2) = (answer, C) when flip (cloud.data = answer | C,
+    // :1306-1314) or (C, answer) otherwise (:1318-1326).  kind = chain_kind(k1, k2, flip),
+    // k1, k2 in {ADD, SUB, RSUB, MUL}.  Inputs: A, B, carry word, C at stage 2's width
+    // (bits, or 2*bits after a MUL) [, C's carry word when !flip].
+    CIRC_CHAIN_BASE = 32,
+    CIRC_CHAIN_END = 64,
 };
+constexpr int32_t chain_kind(int32_t k1, int32_t k2, bool flip) { return CIRC_CHAIN_BASE + (k1 - 1) + 4 * (k2 - 1) + (flip ? 0 : 16); }
+// decodes a CHAIN kind (CIRC_MULADD counts as chain(MUL, ADD, flip)); false for plain kinds
+bool decode_chain(int32_t kind, int32_t* k1, int32_t* k2, bool* flip);
 
 // bits: operand width.  ADD/SUB/RSUB accept any bits >= 1 (the reference uses
 // 32/64/128/256; 16 is BASELINE.json's generalisation add(...,16,...));
 // MUL accepts 32/64/128.  Returns false for unsupported combinations.
 // balanced=true lets the builder pick the slack-balanced schedule where it saves memory
 // (64/128-bit multipliers); false forces plain ASAP levels.
-bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced = true);
+// fold=true: constant-folded / gate-shared variant (decrypt-identical, fewer bootstraps; opt-in).
+bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced = true, bool fold = false);
 // number of input / output samples per expression of a circuit kind
 int32_t circuit_n_inputs(int32_t kind, int32_t bits);
 int32_t circuit_n_outputs(int32_t kind, int32_t bits);

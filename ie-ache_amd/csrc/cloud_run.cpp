@@ -122,9 +122,7 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
     if (int_negative == 1) ciphernegative = 1;
     if (int_negative == 2) ciphernegative = 2;
     if (int_negative == 3) ciphernegative = 4;
-    std::random_device rd;
-    const uint32_t seed_words[4] = {rd(), rd(), rd(), rd()};
-    Rng rng(seed_words, 4);
+    Rng rng = Rng::secure();  // these samples leave the process: ChaCha20 keyed from the kernel
     std::vector<Torus32> word(WORD);
     for (int i = 0; i < 32; i++)  // :822-824 fresh encryption under the nbit key
         lwe_encrypt_bit(np, nbit.lwe_key.data(), (ciphernegative >> i) & 1, rng, word.data() + i * S);
@@ -190,8 +188,12 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
     if (const char* adder = getenv("IEACHE_ADDER")) {
         if (std::string(adder) == "kogge-stone" && kind >= CIRC_ADD && kind <= CIRC_RSUB) kind += CIRC_ADD_KS - CIRC_ADD;
     }
+    // Opt-in constant folding (SURVEY App. C note): fewer bootstraps, same decrypted answer, not the
+    // reference's ciphertext bits
+    const char* fold_env = getenv("IEACHE_FOLD");
+    const bool fold = fold_env && fold_env[0] && fold_env[0] != '0';
     Circuit circ;
-    if (!build_circuit(kind, int_bit, &circ)) return 0;
+    if (!build_circuit(kind, int_bit, &circ, true, fold)) return 0;
     const int W = int_bit / 32;
     // circuit inputs: operand-1 words, operand-2 words, ciphertextcarry1
     std::vector<Torus32> in((size_t)circ.n_inputs * S);

@@ -1,6 +1,12 @@
 // See codec.h.
 #include "codec.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
@@ -36,31 +42,6 @@ void write_section(FILE* f, const char* title, const Props& props) {
     fprintf(f, "-----BEGIN %s-----\n", title);
     for (const auto& kv : props) fprintf(f, "%s: %s\n", kv.first.c_str(), kv.second.c_str());
     fprintf(f, "-----END %s-----\n", title);
-}
-
-std::string read_line(FILE* f) {
-    std::string s;
-    int c;
-    while ((c = fgetc(f)) != EOF && c != '\n') s.push_back((char)c);
-    if (c == EOF && s.empty()) throw CodecError("unexpected end of file in text section");
-    if (!s.empty() && s.back() == '\r') s.pop_back();
-    return s;
-}
-
-Props read_section(FILE* f, const char* title) {
-    const std::string begin = std::string("-----BEGIN ") + title + "-----";
-    const std::string end = std::string("-----END ") + title + "-----";
-    std::string line = read_line(f);
-    if (line != begin) throw CodecError("expected '" + begin + "', got '" + line.substr(0, 60) + "'");
-    Props p;
-    for (;;) {
-        line = read_line(f);
-        if (line == end) break;
-        const size_t colon = line.find(": ");
-        if (colon == std::string::npos) throw CodecError("malformed property line in " + std::string(title));
-        p[line.substr(0, colon)] = line.substr(colon + 2);
-    }
-    return p;
 }
 
 std::string fmt_double(double v) {
@@ -100,39 +81,18 @@ void write_lwe_samples(FILE* f, int32_t n, size_t count, const Torus32* rows, si
     }
 }
 
-// libtfhe write_tfheGateBootstrappingParameters: GATEBOOTSPARAMS, LWEPARAMS,
-// TGSWPARAMS, TLWEPARAMS
+// libtfhe write_tfheGateBootstrappingParameters: GATEBOOTSPARAMS, LWEPARAMS, then
+// write_tGswParams = TLWEPARAMS followed by TGSWPARAMS
 void write_params(FILE* f, const Params& p) {
     write_section(f, "GATEBOOTSPARAMS", {{"ks_basebit", std::to_string(p.ks_basebit)}, {"ks_t", std::to_string(p.ks_t)}});
     write_section(f, "LWEPARAMS", {{"alpha_max", fmt_double(p.lwe_alpha_max)},
                                     {"alpha_min", fmt_double(p.lwe_alpha_min)},
                                     {"n", std::to_string(p.n)}});
-    write_section(f, "TGSWPARAMS", {{"Bgbit", std::to_string(p.Bgbit)}, {"l", std::to_string(p.l)}});
     write_section(f, "TLWEPARAMS", {{"N", std::to_string(p.N)},
                                      {"alpha_max", fmt_double(p.tlwe_alpha_max)},
                                      {"alpha_min", fmt_double(p.tlwe_alpha_min)},
                                      {"k", std::to_string(p.k)}});
-}
-
-Params read_params(FILE* f) {
-    Params p;
-    Props s = read_section(f, "GATEBOOTSPARAMS");
-    p.ks_t = prop_int(s, "ks_t");
-    p.ks_basebit = prop_int(s, "ks_basebit");
-    s = read_section(f, "LWEPARAMS");
-    p.n = prop_int(s, "n");
-    p.lwe_alpha_min = prop_double(s, "alpha_min");
-    p.lwe_alpha_max = prop_double(s, "alpha_max");
-    s = read_section(f, "TGSWPARAMS");
-    p.l = prop_int(s, "l");
-    p.Bgbit = prop_int(s, "Bgbit");
-    s = read_section(f, "TLWEPARAMS");
-    p.N = prop_int(s, "N");
-    p.k = prop_int(s, "k");
-    p.tlwe_alpha_min = prop_double(s, "alpha_min");
-    p.tlwe_alpha_max = prop_double(s, "alpha_max");
-    if (!p.supported()) throw CodecError("parameter set in key header is not supported");
-    return p;
+    write_section(f, "TGSWPARAMS", {{"Bgbit", std::to_string(p.Bgbit)}, {"l", std::to_string(p.l)}});
 }
 
 // libtfhe write_lweBootstrappingKey_content: tag, key-switch key (tag, max
@@ -149,35 +109,9 @@ static void write_cloud_body(FILE* f, const CloudKeyData& ck) {
     xwrite(f, ck.bk.data(), ck.bk.size() * 4);
 }
 
-static void read_cloud_body(FILE* f, const Params& p, CloudKeyData* ck) {
-    double var;
-    expect_uid(f, kLweBootstrappingKeyUid, "bootstrapping key");
-    expect_uid(f, kLweKeySwitchKeyUid, "key-switch key");
-    xread(f, &var, 8, "key-switch variance");
-    if (ck) {
-        ck->p = p;
-        ck->ksk.resize(p.ksk_count());
-        xread(f, ck->ksk.data(), ck->ksk.size() * 4, "key-switch key body");
-    } else if (fseek(f, (long)(p.ksk_count() * 4), SEEK_CUR) != 0) {
-        throw CodecError("seek failed in key-switch key body");
-    }
-    xread(f, &var, 8, "bootstrapping key variance");
-    if (ck) {
-        ck->bk.resize(p.bk_count());
-        xread(f, ck->bk.data(), ck->bk.size() * 4, "bootstrapping key body");
-    } else if (fseek(f, (long)(p.bk_count() * 4), SEEK_CUR) != 0) {
-        throw CodecError("seek failed in bootstrapping key body");
-    }
-}
-
 void write_cloud_key(FILE* f, const CloudKeyData& ck) {
     write_params(f, ck.p);
     write_cloud_body(f, ck);
-}
-
-void read_cloud_key(FILE* f, CloudKeyData* ck) {
-    const Params p = read_params(f);
-    read_cloud_body(f, p, ck);
 }
 
 // libtfhe write_tfheGateBootstrappingSecretKeySet: cloud key set, LWE key, TGSW key
@@ -191,23 +125,11 @@ void write_secret_key(FILE* f, const SecretKeyData& sk) {
     xwrite(f, sk.tlwe_key.data(), sk.tlwe_key.size() * 4);
 }
 
-void read_secret_key(FILE* f, SecretKeyData* sk, bool with_cloud) {
-    sk->p = read_params(f);
-    read_cloud_body(f, sk->p, with_cloud ? &sk->cloud : nullptr);
-    if (!with_cloud) {
-        sk->cloud.p = sk->p;
-        sk->cloud.bk.clear();
-        sk->cloud.ksk.clear();
-    }
-    expect_uid(f, kLweKeyUid, "LWE key");
-    sk->lwe_key.resize(sk->p.n);
-    xread(f, sk->lwe_key.data(), sk->lwe_key.size() * 4, "LWE key bits");
-    expect_uid(f, kTGswKeyUid, "TGSW key");
-    sk->tlwe_key.resize((size_t)sk->p.k * sk->p.N);
-    xread(f, sk->tlwe_key.data(), sk->tlwe_key.size() * 4, "TGSW key bits");
-}
-
+// ------------------------------------------------------------------------
+// Tolerant reader
+// ------------------------------------------------------------------------
 namespace {
+
 struct File {
     FILE* f;
     File(const std::string& path, const char* mode) : f(fopen(path.c_str(), mode)) {
@@ -217,23 +139,435 @@ struct File {
         if (f) fclose(f);
     }
 };
+
+// read-only mapping of a whole file
+struct Mapped {
+    const unsigned char* data = nullptr;
+    size_t size = 0;
+    explicit Mapped(const std::string& path) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw CodecError("cannot open " + path + ": " + strerror(errno));
+        struct stat st;
+        if (fstat(fd, &st) != 0) {
+            close(fd);
+            throw CodecError("cannot stat " + path);
+        }
+        size = (size_t)st.st_size;
+        if (size) {
+            void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                close(fd);
+                throw CodecError("cannot map " + path + ": " + strerror(errno));
+            }
+            data = static_cast<const unsigned char*>(m);
+        }
+        close(fd);
+    }
+    ~Mapped() {
+        if (data) munmap(const_cast<unsigned char*>(data), size);
+    }
+    Mapped(const Mapped&) = delete;
+    Mapped& operator=(const Mapped&) = delete;
+};
+
+struct TextSection {
+    std::string title;
+    Props props;
+    size_t begin, end;  // byte range in the file, END line and its newline included
+};
+
+// Finds every "-----BEGIN T-----\n ... -----END T-----\n" block.  A 16-byte ASCII marker turning
+// up inside key material by chance has probability ~2^-100 per position; a candidate must also
+// parse completely (printable "name: value" lines up to its END line) to count.
+std::vector<TextSection> scan_sections(const Mapped& m) {
+    static const char kBegin[] = "-----BEGIN ";
+    const size_t blen = sizeof(kBegin) - 1;
+    std::vector<TextSection> out;
+    size_t pos = 0;
+    while (pos + blen < m.size) {
+        const void* hit = memmem(m.data + pos, m.size - pos, kBegin, blen);
+        if (!hit) break;
+        const size_t at = (size_t)(static_cast<const unsigned char*>(hit) - m.data);
+        pos = at + 1;
+        auto line_at = [&](size_t from, std::string* line) -> size_t {  // returns position after '\n', 0 on failure
+            line->clear();
+            for (size_t i = from; i < m.size && i < from + 256; i++) {
+                const unsigned char ch = m.data[i];
+                if (ch == '\n') return i + 1;
+                if (ch == '\r') continue;
+                if (ch < 0x20 || ch > 0x7e) return 0;
+                line->push_back((char)ch);
+            }
+            return 0;
+        };
+        std::string line;
+        size_t next = line_at(at, &line);
+        if (!next || line.size() < blen + 6 || line.compare(line.size() - 5, 5, "-----") != 0) continue;
+        TextSection s;
+        s.title = line.substr(blen, line.size() - blen - 5);
+        s.begin = at;
+        const std::string endline = "-----END " + s.title + "-----";
+        bool ok = false;
+        for (int guard = 0; guard < 64; guard++) {
+            const size_t after = line_at(next, &line);
+            if (!after) break;
+            next = after;
+            if (line == endline) {
+                ok = true;
+                break;
+            }
+            const size_t colon = line.find(": ");
+            if (colon == std::string::npos) break;
+            s.props[line.substr(0, colon)] = line.substr(colon + 2);
+        }
+        if (!ok) continue;
+        s.end = next;
+        out.push_back(std::move(s));
+        pos = next;
+    }
+    return out;
+}
+
+const TextSection* find_section(const std::vector<TextSection>& secs, const char* title) {
+    for (const auto& s : secs)
+        if (s.title == title) return &s;  // the first one: the gate-bootstrapping header comes first in every layout
+    return nullptr;
+}
+
+Params params_from_sections(const std::vector<TextSection>& secs) {
+    Params p;
+    const TextSection* g = find_section(secs, "GATEBOOTSPARAMS");
+    const TextSection* lw = find_section(secs, "LWEPARAMS");
+    const TextSection* tg = find_section(secs, "TGSWPARAMS");
+    const TextSection* tl = find_section(secs, "TLWEPARAMS");
+    for (const auto& need : {std::make_pair(g, "GATEBOOTSPARAMS"), std::make_pair(lw, "LWEPARAMS"),
+                             std::make_pair(tg, "TGSWPARAMS"), std::make_pair(tl, "TLWEPARAMS")})
+        if (!need.first) throw CodecError(std::string("key header has no ") + need.second + " section");
+    p.ks_t = prop_int(g->props, "ks_t");
+    p.ks_basebit = prop_int(g->props, "ks_basebit");
+    p.n = prop_int(lw->props, "n");
+    p.lwe_alpha_min = prop_double(lw->props, "alpha_min");
+    p.lwe_alpha_max = prop_double(lw->props, "alpha_max");
+    p.l = prop_int(tg->props, "l");
+    p.Bgbit = prop_int(tg->props, "Bgbit");
+    p.N = prop_int(tl->props, "N");
+    p.k = prop_int(tl->props, "k");
+    p.tlwe_alpha_min = prop_double(tl->props, "alpha_min");
+    p.tlwe_alpha_max = prop_double(tl->props, "alpha_max");
+    if (!p.supported()) throw CodecError("parameter set in key header is not supported");
+    // an LWEKSPARAMS section (libtfhe writes one in front of a stand-alone key-switch key), if present, must agree
+    if (const TextSection* ks = find_section(secs, "LWEKSPARAMS")) {
+        auto has = [&](const char* k) { return ks->props.count(k) != 0; };
+        if ((has("t") && prop_int(ks->props, "t") != p.ks_t) || (has("basebit") && prop_int(ks->props, "basebit") != p.ks_basebit))
+            throw CodecError("LWEKSPARAMS disagrees with GATEBOOTSPARAMS");
+    }
+    return p;
+}
+
+// the file minus its text sections, addressed as one contiguous byte stream
+struct BinaryStream {
+    const Mapped& m;
+    std::vector<std::pair<size_t, size_t>> spans;  // [begin, end) in the file
+    size_t total = 0;
+    BinaryStream(const Mapped& mm, const std::vector<TextSection>& secs) : m(mm) {
+        size_t at = 0;
+        for (const auto& s : secs) {
+            if (s.begin > at) spans.emplace_back(at, s.begin);
+            at = s.end;
+        }
+        if (m.size > at) spans.emplace_back(at, m.size);
+        for (const auto& sp : spans) total += sp.second - sp.first;
+    }
+    void read(size_t pos, size_t len, void* dst) const {
+        unsigned char* out = static_cast<unsigned char*>(dst);
+        for (const auto& sp : spans) {
+            const size_t slen = sp.second - sp.first;
+            if (pos >= slen) {
+                pos -= slen;
+                continue;
+            }
+            const size_t take = std::min(len, slen - pos);
+            memcpy(out, m.data + sp.first + pos, take);
+            out += take;
+            len -= take;
+            pos = 0;
+            if (!len) return;
+        }
+        if (len) throw CodecError("short read: key body");
+    }
+    int32_t i32(size_t pos) const {
+        int32_t v;
+        read(pos, 4, &v);
+        return v;
+    }
+};
+
+enum FieldKind { F_UID, F_VAR, F_KSK, F_BK, F_LWEKEY, F_TGSWKEY };
+struct Field {
+    FieldKind kind;
+    int32_t uid = 0;          // F_UID: expected tag
+    bool skip_d0 = false;     // F_KSK: the d = 0 entries are not in the file
+    bool sample_var = false;  // F_KSK / F_BK: a variance double follows every sample / TLWE row
+    std::string name;
+};
+struct Layout {
+    std::vector<Field> fields;
+    std::string desc;
+    size_t bytes(const Params& p) const {
+        size_t b = 0;
+        for (const Field& f : fields) b += field_bytes(f, p);
+        return b;
+    }
+    static size_t field_bytes(const Field& f, const Params& p) {
+        switch (f.kind) {
+            case F_UID: return 4;
+            case F_VAR: return 8;
+            case F_KSK: {
+                const size_t samples = (size_t)p.k * p.N * p.ks_t * (p.ks_base() - (f.skip_d0 ? 1 : 0));
+                return samples * ((size_t)(p.n + 1) * 4 + (f.sample_var ? 8 : 0));
+            }
+            case F_BK: {
+                const size_t rows = (size_t)p.n * p.kpl();
+                return rows * ((size_t)(p.k + 1) * p.N * 4 + (f.sample_var ? 8 : 0));
+            }
+            case F_LWEKEY: return (size_t)p.n * 4;
+            case F_TGSWKEY: return (size_t)p.k * p.N * 4;
+        }
+        return 0;
+    }
+};
+
+// every cloud-key body layout considered; this build's own writer is hypothesis 0
+std::vector<Layout> cloud_body_layouts() {
+    std::vector<Layout> out;
+    for (int ks_first = 1; ks_first >= 0; ks_first--)
+        for (int bk_uid = 1; bk_uid >= 0; bk_uid--)
+            for (int ks_uid = 1; ks_uid >= 0; ks_uid--)
+                for (int ks_var = 1; ks_var <= 3; ks_var++)          // 1: one double, 2: none, 3: one per sample
+                    for (int skip_d0 = 0; skip_d0 <= 1; skip_d0++)
+                        for (int bk_var = 1; bk_var <= 3; bk_var++) {  // 1: one double, 2: none, 3: one per TLWE row
+                            Layout L;
+                            auto uid = [&](int32_t v, const char* nm) {
+                                Field f{F_UID};
+                                f.uid = v;
+                                f.name = nm;
+                                L.fields.push_back(f);
+                            };
+                            auto ks = [&] {
+                                if (ks_uid) uid(kLweKeySwitchKeyUid, "key-switch tag");
+                                if (ks_var == 1) L.fields.push_back(Field{F_VAR});
+                                Field f{F_KSK};
+                                f.skip_d0 = skip_d0;
+                                f.sample_var = ks_var == 3;
+                                L.fields.push_back(f);
+                            };
+                            auto bk = [&] {
+                                if (bk_var == 1) L.fields.push_back(Field{F_VAR});
+                                Field f{F_BK};
+                                f.sample_var = bk_var == 3;
+                                L.fields.push_back(f);
+                            };
+                            if (bk_uid) uid(kLweBootstrappingKeyUid, "bootstrapping-key tag");
+                            if (ks_first) {
+                                ks();
+                                bk();
+                            } else {
+                                bk();
+                                ks();
+                            }
+                            static const char* vn[4] = {"", "one variance", "no variance", "variance per sample"};
+                            L.desc = std::string(bk_uid ? "bk tag, " : "") + (ks_first ? "KS{" : "BK{") +
+                                     (ks_first ? std::string(ks_uid ? "tag, " : "") + vn[ks_var] + (skip_d0 ? ", d=0 rows omitted" : ", all base rows")
+                                               : std::string(vn[bk_var])) +
+                                     "} then " + (ks_first ? "BK{" : "KS{") +
+                                     (ks_first ? std::string(vn[bk_var])
+                                               : std::string(ks_uid ? "tag, " : "") + vn[ks_var] + (skip_d0 ? ", d=0 rows omitted" : ", all base rows")) +
+                                     "}";
+                            out.push_back(std::move(L));
+                        }
+    return out;
+}
+
+std::vector<Layout> secret_layouts() {
+    std::vector<Layout> out;
+    const std::vector<Layout> bodies = cloud_body_layouts();
+    for (int cloud_first = 1; cloud_first >= 0; cloud_first--)
+        for (int lwe_first = 1; lwe_first >= 0; lwe_first--)
+            for (int key_uids = 1; key_uids >= 0; key_uids--)
+                for (const Layout& body : bodies) {
+                    Layout L;
+                    auto keys = [&] {
+                        for (int q = 0; q < 2; q++) {
+                            const bool lwe = (q == 0) == (lwe_first != 0);
+                            if (key_uids) {
+                                Field u{F_UID};
+                                u.uid = lwe ? kLweKeyUid : kTGswKeyUid;
+                                u.name = lwe ? "LWE key tag" : "TGSW key tag";
+                                L.fields.push_back(u);
+                            }
+                            L.fields.push_back(Field{lwe ? F_LWEKEY : F_TGSWKEY});
+                        }
+                    };
+                    if (!cloud_first) keys();
+                    L.fields.insert(L.fields.end(), body.fields.begin(), body.fields.end());
+                    if (cloud_first) keys();
+                    L.desc = std::string(cloud_first ? "cloud body [" : "secret keys, then cloud body [") + body.desc + "]" +
+                             (cloud_first ? ", then " : "; ") + (lwe_first ? "LWE key, TGSW key" : "TGSW key, LWE key") +
+                             (key_uids ? " (tagged)" : " (untagged)");
+                    out.push_back(std::move(L));
+                }
+    return out;
+}
+
+thread_local std::string g_layout;
+
+// Chooses the layout whose byte count equals the binary part of the file and whose tags / key bits
+// check out, then decodes it.  Any output pointer may be null (that array is only located).
+void decode(const std::string& path, const std::vector<Layout>& candidates, const Params& p, const BinaryStream& bin,
+            CloudKeyData* ck, SecretKeyData* sk) {
+    const Layout* chosen = nullptr;
+    size_t size_matches = 0;
+    std::string why;
+    for (const Layout& L : candidates) {
+        if (L.bytes(p) != bin.total) continue;
+        size_matches++;
+        bool ok = true;
+        size_t pos = 0;
+        for (const Field& f : L.fields) {
+            if (f.kind == F_UID && bin.i32(pos) != f.uid) {
+                if (why.empty()) why = "expected " + f.name + " " + std::to_string(f.uid) + ", found " + std::to_string(bin.i32(pos));
+                ok = false;
+                break;
+            }
+            if (f.kind == F_VAR || ((f.kind == F_KSK || f.kind == F_BK) && f.sample_var)) {
+                // a variance is -1 (libtfhe's "unset"), 0, or a small positive number; 8 bytes of key
+                // material pass this with probability ~2 %, which separates layouts of equal size
+                // that differ only in where the doubles stand
+                const size_t at = f.kind == F_VAR ? pos
+                                  : pos + (f.kind == F_KSK ? (size_t)(p.n + 1) * 4 : (size_t)(p.k + 1) * p.N * 4);
+                double v;
+                bin.read(at, 8, &v);
+                if (!(v == -1.0 || (v >= 0.0 && v < 1.0))) {
+                    if (why.empty()) why = "a variance field holds an implausible value";
+                    ok = false;
+                    break;
+                }
+            }
+            if (f.kind == F_LWEKEY || f.kind == F_TGSWKEY) {  // secret keys are bits
+                const size_t cnt = Layout::field_bytes(f, p) / 4;
+                for (size_t i = 0; i < cnt && ok; i++) {
+                    const int32_t v = bin.i32(pos + 4 * i);
+                    if (v != 0 && v != 1) ok = false;
+                }
+                if (!ok) {
+                    if (why.empty()) why = "secret-key words are not bits";
+                    break;
+                }
+            }
+            pos += Layout::field_bytes(f, p);
+        }
+        if (ok) {
+            chosen = &L;
+            break;  // candidates are ordered by preference (this build's writer first)
+        }
+    }
+    if (!chosen) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s: no key layout fits: %zu binary bytes for n=%d N=%d k=%d l=%d t=%d basebit=%d (%zu of %zu hypotheses match the size%s%s)",
+                 path.c_str(), bin.total, p.n, p.N, p.k, p.l, p.ks_t, p.ks_basebit, size_matches, candidates.size(),
+                 why.empty() ? "" : "; ", why.c_str());
+        throw CodecError(buf);
+    }
+    g_layout = chosen->desc;
+    size_t pos = 0;
+    for (const Field& f : chosen->fields) {
+        const size_t fb = Layout::field_bytes(f, p);
+        switch (f.kind) {
+            case F_KSK:
+                if (ck) {
+                    ck->ksk.assign(p.ksk_count(), 0);
+                    const size_t S = (size_t)p.n + 1, base = (size_t)p.ks_base();
+                    const size_t rec = S * 4 + (f.sample_var ? 8 : 0);
+                    if (!f.skip_d0 && !f.sample_var) {
+                        bin.read(pos, fb, ck->ksk.data());
+                    } else {
+                        size_t src = pos;
+                        for (size_t ij = 0; ij < (size_t)p.k * p.N * p.ks_t; ij++)
+                            for (size_t d = f.skip_d0 ? 1 : 0; d < base; d++, src += rec)
+                                bin.read(src, S * 4, ck->ksk.data() + (ij * base + d) * S);
+                    }
+                }
+                break;
+            case F_BK:
+                if (ck) {
+                    ck->bk.resize(p.bk_count());
+                    const size_t row = (size_t)(p.k + 1) * p.N;
+                    if (!f.sample_var) {
+                        bin.read(pos, fb, ck->bk.data());
+                    } else {
+                        for (size_t r = 0; r < (size_t)p.n * p.kpl(); r++)
+                            bin.read(pos + r * (row * 4 + 8), row * 4, ck->bk.data() + r * row);
+                    }
+                }
+                break;
+            case F_LWEKEY:
+                if (sk) {
+                    sk->lwe_key.resize(p.n);
+                    bin.read(pos, fb, sk->lwe_key.data());
+                }
+                break;
+            case F_TGSWKEY:
+                if (sk) {
+                    sk->tlwe_key.resize((size_t)p.k * p.N);
+                    bin.read(pos, fb, sk->tlwe_key.data());
+                }
+                break;
+            default:
+                break;
+        }
+        pos += fb;
+    }
+}
+
 }  // namespace
+
+const std::string& last_key_layout() { return g_layout; }
+
+Params load_params(const std::string& path) {
+    Mapped m(path);
+    return params_from_sections(scan_sections(m));
+}
+
+void load_cloud_key(const std::string& path, CloudKeyData* ck) {
+    Mapped m(path);
+    const std::vector<TextSection> secs = scan_sections(m);
+    const Params p = params_from_sections(secs);
+    const BinaryStream bin(m, secs);
+    ck->p = p;
+    static const std::vector<Layout> layouts = cloud_body_layouts();
+    decode(path, layouts, p, bin, ck, nullptr);
+}
+
+void load_secret_key(const std::string& path, SecretKeyData* sk, bool with_cloud) {
+    Mapped m(path);
+    const std::vector<TextSection> secs = scan_sections(m);
+    const Params p = params_from_sections(secs);
+    const BinaryStream bin(m, secs);
+    sk->p = p;
+    sk->cloud.p = p;
+    sk->cloud.bk.clear();
+    sk->cloud.ksk.clear();
+    static const std::vector<Layout> layouts = secret_layouts();
+    decode(path, layouts, p, bin, with_cloud ? &sk->cloud : nullptr, sk);
+}
 
 void save_cloud_key(const std::string& path, const CloudKeyData& ck) {
     File f(path, "wb");
     write_cloud_key(f.f, ck);
 }
-void load_cloud_key(const std::string& path, CloudKeyData* ck) {
-    File f(path, "rb");
-    read_cloud_key(f.f, ck);
-}
 void save_secret_key(const std::string& path, const SecretKeyData& sk) {
     File f(path, "wb");
     write_secret_key(f.f, sk);
-}
-void load_secret_key(const std::string& path, SecretKeyData* sk, bool with_cloud) {
-    File f(path, "rb");
-    read_secret_key(f.f, sk, with_cloud);
 }
 
 }  // namespace ieache

@@ -42,20 +42,31 @@ void write_lwe_samples(FILE* f, int32_t n, size_t count, const Torus32* rows, si
                        const double* var = nullptr);
 
 // ---- parameter header (text sections) ----
+// Writer: libtfhe's order as best known (tfhe_io.cpp write_tfheGateBootstrappingParameters ->
+// GATEBOOTSPARAMS, LWEPARAMS, then write_tGswParams, which emits its TLWEPARAMS before TGSWPARAMS).
 void write_params(FILE* f, const Params& p);
-Params read_params(FILE* f);
 
 // ---- key files ----
+// Writers (the layout this build's tools produce; fixtures are written with it).
 void write_cloud_key(FILE* f, const CloudKeyData& ck);
-void read_cloud_key(FILE* f, CloudKeyData* ck);
 void write_secret_key(FILE* f, const SecretKeyData& sk);
-// with_cloud=false skips over the cloud-key body without keeping it
-void read_secret_key(FILE* f, SecretKeyData* sk, bool with_cloud = false);
-
-// convenience: whole files
 void save_cloud_key(const std::string& path, const CloudKeyData& ck);
-void load_cloud_key(const std::string& path, CloudKeyData* ck);
 void save_secret_key(const std::string& path, const SecretKeyData& sk);
+
+// Readers (SURVEY App. B "codec strategy").  libtfhe is not in the reference tree and no file
+// written by it exists here, so the reader does not assume one layout:
+//   * text sections ("-----BEGIN <TITLE>-----" ... "-----END <TITLE>-----") are located by TITLE,
+//     wherever they stand and in any order; properties are read by name;
+//   * what is left is binary.  Its layout is chosen among enumerated hypotheses -- type tags
+//     present or not, no / one / per-sample variance doubles, key-switch entries with or without
+//     the never-read d = 0 rows, key-switch key before or after the bootstrapping key, secret key
+//     bits before or after the cloud-key body -- by solving for the exact remaining byte count,
+//     then checking every tag the hypothesis expects and that secret-key words are bits.
+// The hypothesis that matched is kept in last_key_layout() (and reported by the C ABI).
+// with_cloud=false locates the cloud-key body without keeping it (nbit.key: metadata only).
+Params load_params(const std::string& path);
+void load_cloud_key(const std::string& path, CloudKeyData* ck);
 void load_secret_key(const std::string& path, SecretKeyData* sk, bool with_cloud = false);
+const std::string& last_key_layout();
 
 }  // namespace ieache

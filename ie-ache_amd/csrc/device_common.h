@@ -27,10 +27,15 @@ struct WorkDesc {
     int32_t n_slots;
     const Torus32* flat_a;  // flat mode: rows [item]
     const Torus32* flat_b;
+    const Torus32* flat_c;  // third operand of bootsMUX (flat_type == kFlatMux)
     Torus32* flat_out;
     int32_t flat_type;
     int64_t item0;
 };
+
+// flat_type of the two blind rotations of bootsMUX(a,b,c) (boot-gates.cpp): item 2g is
+// (0,-1/8) + a + b, item 2g+1 is (0,-1/8) - a + c; neither is key-switched on its own
+constexpr int32_t kFlatMux = 16;
 
 struct GateInst {
     const Torus32* a;
@@ -67,6 +72,15 @@ __device__ __forceinline__ GateInst resolve(const WorkDesc& W, int64_t item, int
         // a constant operand is (0, -1/8): only its b term contributes
         if (!g.a) g.cst += (uint32_t)g.sa * 0xE0000000u;
         if (!g.b) g.cst += (uint32_t)g.sb * 0xE0000000u;
+    } else if (W.flat_type == kFlatMux) {
+        const int64_t gi = item >> 1;
+        const bool second = item & 1;
+        g.cst = 0xE0000000u;
+        g.a = W.flat_a + (size_t)gi * stride;
+        g.b = (second ? W.flat_c : W.flat_b) + (size_t)gi * stride;
+        g.out = nullptr;
+        g.sa = second ? -1 : 1;
+        g.sb = 1;
     } else {
         type = W.flat_type;
         gate_coeffs(type, k, g.cst);

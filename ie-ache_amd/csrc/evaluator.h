@@ -35,6 +35,9 @@ public:
     const Params& params() const { return p_; }
     int device() const { return device_; }
     hipStream_t stream() const { return stream_; }
+    // Orders everything launched later on the evaluator's stream after the work queued so far on
+    // `producer` (the stream that wrote the key / input buffers handed over as device pointers).
+    void wait_for_stream(hipStream_t producer);
 
     // Upload the cloud key.  Raw libtfhe order: bk [n][(k+1)l][k+1][N],
     // ksk [kN][t][base][n+1].  The *_device form takes pointers already in this
@@ -47,6 +50,10 @@ public:
     // int32: out[i] = gate(a[i], b[i]).
     void gates_device(int32_t type, size_t count, const Torus32* d_a, const Torus32* d_b,
                       Torus32* d_out, EvalStats* stats);
+
+    // bootsMUX: out[i] = a[i] ? b[i] : c[i] (two blind rotations + one key switch per gate)
+    void mux_device(size_t count, const Torus32* d_a, const Torus32* d_b, const Torus32* d_c, Torus32* d_out,
+                    EvalStats* stats);
 
     // One circuit on `batch` independent expressions.
     //   d_in  [batch][circuit.n_inputs][lwe_stride]
@@ -79,6 +86,8 @@ public:
     struct Impl;  // device buffers; defined in evaluator.hip
 
 private:
+    void init();
+    void destroy();
     Params p_;
     int device_;
     hipStream_t stream_ = nullptr;

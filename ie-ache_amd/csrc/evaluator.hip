@@ -447,6 +447,17 @@ __global__ __launch_bounds__(256) void k_keyswitch_batch(DevKeys K, WorkDesc W, 
     }
 }
 
+// bootsMUX: u = (0, 1/8) + u1 + u2 over the extracted samples of the two blind rotations of a gate
+// (rows 2g and 2g+1 of `ext`), written to row g of `dst`; the key switch follows on `dst`
+__global__ void k_mux_combine(const Torus32* ext, Torus32* dst, int32_t N) {
+    const size_t g = blockIdx.x;
+    const Torus32* u1 = ext + (2 * g) * (size_t)(N + 4);
+    const Torus32* u2 = u1 + (N + 4);
+    Torus32* d = dst + g * (size_t)(N + 4);
+    for (int32_t j = threadIdx.x; j <= N; j += blockDim.x)
+        d[j] = (int32_t)((uint32_t)u1[j] + (uint32_t)u2[j] + (j == N ? (uint32_t)kMU : 0u));
+}
+
 // outputs of a circuit: out[b][o] = +-store[b][slot] or the constant
 __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus32* store, int32_t n_slots,
                                  Torus32* out, int64_t batch, int32_t stride, int32_t n) {
@@ -473,12 +484,15 @@ struct Evaluator::Impl {
     DevKeys K{};
     double2* bkf = nullptr;
     double2* bkf_w64 = nullptr;  // spectrum in the wave-per-gate kernel's layout
+    double2* tw_w64 = nullptr;   // its twiddle table
     bool use_w64 = false;
     bool force_generic_ks = false;
     int32_t* ksk = nullptr;
     double2* twist = nullptr;
     double2* wtab = nullptr;
     Torus32* ext = nullptr;
+    Torus32* ext_mux = nullptr;  // bootsMUX: combined extracted samples, chunk/2 rows
+    size_t ext_mux_items = 0;
     void* br_state = nullptr;  // sliced blind rotation: accumulators + rotation amounts
     size_t br_state_items = 0;
     size_t chunk = 16384;
@@ -505,6 +519,17 @@ struct Evaluator::Impl {
 };
 
 Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(new Impl) {
+    try {
+        init();
+    } catch (...) {
+        destroy();  // the destructor does not run for a half-built object
+        throw;
+    }
+}
+
+void Evaluator::init() {
+    const Params& p = p_;
+    const int device = device_;
     if (!p.supported()) throw std::invalid_argument("unsupported TFHE parameter set");
     int count = 0;
     HIP_CHECK(hipGetDeviceCount(&count));
@@ -571,22 +596,38 @@ Evaluator::Evaluator(const Params& p, int device) : p_(p), device_(device), d_(n
     }
 }
 
-Evaluator::~Evaluator() {
+Evaluator::~Evaluator() { destroy(); }
+
+void Evaluator::destroy() {
     if (!d_) return;
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     (void)hipFree(d_->bkf);
     (void)hipFree(d_->bkf_w64);
+    (void)hipFree(d_->tw_w64);
     (void)hipFree(d_->ksk);
     (void)hipFree(d_->twist);
     (void)hipFree(d_->wtab);
     (void)hipFree(d_->ext);
+    (void)hipFree(d_->ext_mux);
     (void)hipFree(d_->br_state);
     (void)hipFree(d_->store);
     (void)hipFree(d_->d_gates);
     (void)hipFree(d_->d_outs);
     if (stream_) (void)hipStreamDestroy(stream_);
+    stream_ = nullptr;
     delete d_;
+    d_ = nullptr;
+}
+
+void Evaluator::wait_for_stream(hipStream_t producer) {
+    HIP_CHECK(hipSetDevice(device_));
+    hipEvent_t ev;
+    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, producer);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream_, ev, 0);
+    (void)hipEventDestroy(ev);
+    HIP_CHECK(e);
 }
 
 void Evaluator::set_chunk(size_t items) {
@@ -659,6 +700,11 @@ void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
     HIP_CHECK(hipGetLastError());
     if (w64::supported(p_)) {
         if (!d_->bkf_w64) HIP_CHECK(hipMalloc(&d_->bkf_w64, w64::spectrum_elems(p_) * sizeof(double2)));
+        if (!d_->tw_w64) {
+            HIP_CHECK(hipMalloc(&d_->tw_w64, w64::twiddle_table_elems() * sizeof(double2)));
+            w64::build_twiddle_table(d_->tw_w64, stream_);
+            HIP_CHECK(hipGetLastError());
+        }
         w64::prepare_spectrum(p_, d_bk, d_->bkf_w64, stream_);
         HIP_CHECK(hipGetLastError());
     }
@@ -710,8 +756,8 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
         }
         if (d->br_variant == 0 && cnt <= d->br_wide_max)
             return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, w64::bara_stride(p), w64::kVariantWide,
-                               stream);
-        return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, d->br_slice, d->br_variant, stream);
+                               d->tw_w64, stream);
+        return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, d->br_slice, d->br_variant, d->tw_w64, stream);
     }
     else
         hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,
@@ -795,6 +841,67 @@ void Evaluator::gates_device(int32_t type, size_t count, const Torus32* d_a, con
     tall.mark();
     HIP_CHECK(hipStreamSynchronize(stream_));
     if (stats) {
+        stats->total_ms += tall.sum_ms();
+        stats->blind_rotate_ms += tbr.sum_ms();
+        stats->keyswitch_ms += tks.sum_ms();
+        stats->levels += 1;
+    }
+}
+
+// bootsMUX (boot-gates.cpp): two blind rotations per gate, their extracted samples added, one key switch
+void Evaluator::mux_device(size_t count, const Torus32* d_a, const Torus32* d_b, const Torus32* d_c, Torus32* d_out,
+                           EvalStats* stats) {
+    if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
+    HIP_CHECK(hipSetDevice(device_));
+    if (count == 0) return;
+    d_->use_w64 = w64::supported(p_) && !force_generic_;
+    d_->force_generic_ks = force_generic_;
+    const DevKeys& K = d_->K;
+    const size_t chunk = std::max<size_t>(d_->chunk & ~(size_t)1, 2), gates_per_chunk = chunk / 2;
+    if (d_->ext_items < chunk) {
+        if (d_->ext) HIP_CHECK(hipFree(d_->ext));
+        d_->ext = nullptr;
+        d_->ext_items = 0;
+        HIP_CHECK(hipMalloc(&d_->ext, chunk * (size_t)(K.N + 4) * 4));
+        d_->ext_items = chunk;
+    }
+    if (d_->ext_mux_items < gates_per_chunk) {
+        if (d_->ext_mux) HIP_CHECK(hipFree(d_->ext_mux));
+        d_->ext_mux = nullptr;
+        d_->ext_mux_items = 0;
+        HIP_CHECK(hipMalloc(&d_->ext_mux, gates_per_chunk * (size_t)(K.N + 4) * 4));
+        d_->ext_mux_items = gates_per_chunk;
+    }
+    Timer tall(stats != nullptr, stream_), tbr(stats != nullptr, stream_), tks(stats != nullptr, stream_);
+    tall.mark();
+    for (size_t done = 0; done < count; done += gates_per_chunk) {
+        const int64_t cnt = (int64_t)std::min(gates_per_chunk, count - done);
+        WorkDesc W{};
+        W.flat_a = d_a + done * K.stride;
+        W.flat_b = d_b + done * K.stride;
+        W.flat_c = d_c + done * K.stride;
+        W.flat_type = kFlatMux;
+        W.item0 = 0;
+        tbr.mark();
+        const int nbr = launch_blind_rotate(p_, d_, stream_, W, 2 * cnt, d_->ext, -1, nullptr);
+        tbr.mark();
+        HIP_CHECK(hipGetLastError());
+        tks.mark();
+        hipLaunchKernelGGL(k_mux_combine, dim3((unsigned)cnt), dim3(256), 0, stream_, d_->ext, d_->ext_mux, K.N);
+        WorkDesc Wk{};
+        launch_keyswitch(d_, stream_, Wk, cnt, d_->ext_mux, d_out + done * K.stride, d_->force_generic_ks);
+        tks.mark();
+        HIP_CHECK(hipGetLastError());
+        if (stats) {
+            stats->blind_rotate_launches += nbr;
+            stats->keyswitch_launches++;
+            stats->chunks++;
+        }
+    }
+    tall.mark();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (stats) {
+        stats->bootstraps += 2 * (int64_t)count;  // blind rotations; libtfhe counts a MUX as two bootstraps and one key switch
         stats->total_ms += tall.sum_ms();
         stats->blind_rotate_ms += tbr.sum_ms();
         stats->keyswitch_ms += tks.sum_ms();

@@ -2,8 +2,12 @@
 // evaluator's tools and the metadata handling of the `cloud` shim.
 #include "tfhe_host.h"
 
+#include <sys/random.h>
+
+#include <cerrno>
 #include <cmath>
 #include <cstring>
+#include <stdexcept>
 
 namespace ieache {
 
@@ -24,7 +28,58 @@ Rng::Rng(const uint32_t* seed_words, int count, uint64_t stream) {
     for (int i = 0; i < 4; i++) s_[i] = splitmix64(x);
 }
 
+// ChaCha20 block function (RFC 8439 section 2.3), 64-bit block counter in words 12-13
+void Rng::chacha_refill() {
+    auto rotl32 = [](uint32_t v, int c) { return (v << c) | (v >> (32 - c)); };
+    uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 8; i++) st[4 + i] = key_[i];
+    st[12] = (uint32_t)counter_;
+    st[13] = (uint32_t)(counter_ >> 32);
+    st[14] = nonce_[0];
+    st[15] = nonce_[1];
+    uint32_t x[16];
+    memcpy(x, st, sizeof x);
+    auto qr = [&](int a, int b, int c2, int d) {
+        x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16);
+        x[c2] += x[d]; x[b] = rotl32(x[b] ^ x[c2], 12);
+        x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);
+        x[c2] += x[d]; x[b] = rotl32(x[b] ^ x[c2], 7);
+    };
+    for (int r = 0; r < 10; r++) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) x[i] += st[i];
+    memcpy(buf_, x, sizeof buf_);
+    buf_pos_ = 0;
+    counter_++;
+}
+
+Rng Rng::secure() {
+    Rng r((uint64_t)0);
+    unsigned char seed[44];
+    size_t got = 0;
+    while (got < sizeof seed) {
+        const ssize_t k = getrandom(seed + got, sizeof seed - got, 0);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            throw std::runtime_error("getrandom() failed: no kernel entropy for fresh encryptions");
+        }
+        got += (size_t)k;
+    }
+    memcpy(r.key_, seed, 32);
+    memcpy(r.nonce_, seed + 32, 12);
+    r.chacha_ = true;
+    r.counter_ = 0;
+    r.buf_pos_ = 8;
+    return r;
+}
+
 uint64_t Rng::next() {
+    if (chacha_) {
+        if (buf_pos_ >= 8) chacha_refill();
+        return buf_[buf_pos_++];
+    }
     const uint64_t result = rotl(s_[1] * 5, 7) * 9;
     const uint64_t t = s_[1] << 17;
     s_[2] ^= s_[0];
@@ -100,7 +155,10 @@ static void add_mul_binary_key(int32_t N, uint32_t* b, const Torus32* a, const i
 void keygen(const Params& p, const uint32_t* seed_words, int nseed, SecretKeyData* out,
             bool with_cloud) {
     out->p = p;
-    Rng krng(seed_words, nseed, 0);
+    // nseed < 0: every stream is its own kernel-keyed ChaCha20 generator (nothing reproducible)
+    const bool secure = nseed < 0;
+    auto make_rng = [&](uint64_t stream) { return secure ? Rng::secure() : Rng(seed_words, nseed, stream); };
+    Rng krng = make_rng(0);
     out->lwe_key.resize(p.n);
     for (auto& b : out->lwe_key) b = krng.bit();
     out->tlwe_key.resize((size_t)p.k * p.N);
@@ -116,7 +174,7 @@ void keygen(const Params& p, const uint32_t* seed_words, int nseed, SecretKeyDat
     out->cloud.bk.assign(p.bk_count(), 0);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int32_t i = 0; i < p.n; i++) {
-        Rng rng(seed_words, nseed, 1 + (uint64_t)i);
+        Rng rng = make_rng(1 + (uint64_t)i);
         Torus32* bki = out->cloud.bk.data() + (size_t)i * kpl * (k + 1) * N;
         for (int32_t row = 0; row < kpl; row++) {
             Torus32* a = bki + (size_t)row * (k + 1) * N;  // polys a_0..a_{k-1}, then b
@@ -140,7 +198,7 @@ void keygen(const Params& p, const uint32_t* seed_words, int nseed, SecretKeyDat
     out->cloud.ksk.assign(p.ksk_count(), 0);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int32_t i = 0; i < k * N; i++) {
-        Rng rng(seed_words, nseed, (uint64_t)1 << 32 | (uint64_t)i);
+        Rng rng = make_rng((uint64_t)1 << 32 | (uint64_t)i);
         for (int32_t j = 0; j < p.ks_t; j++)
             for (int32_t d = 1; d < base; d++) {  // d = 0 stays all-zero: never read
                 Torus32* s = out->cloud.ksk.data() + (((size_t)i * p.ks_t + j) * base + d) * (n + 1);

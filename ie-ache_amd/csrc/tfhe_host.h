@@ -10,13 +10,19 @@
 
 namespace ieache {
 
-// xoshiro256** seeded through splitmix64 from a list of 32-bit seed words
-// (the reference seeds libtfhe with {314,1592,657} / {314,1592,888},
-// Keygen/keygen.c:30,34; our generator is documented, not libtfhe's).
+// Two generators behind one interface:
+//  * seeded: xoshiro256** seeded through splitmix64 from a list of 32-bit seed words (the
+//    reference seeds libtfhe with {314,1592,657} / {314,1592,888}, Keygen/keygen.c:30,34; our
+//    generator is documented, not libtfhe's).  Reproducible, NOT cryptographic: for test
+//    vectors and for mirroring keygen.c's fixed seeds only.
+//  * Rng::secure(): a ChaCha20 key stream keyed from the kernel (getrandom(2)).  Used wherever
+//    fresh ciphertexts leave the process (the metadata words main() re-encrypts under the nbit
+//    key, cloud.c:822-824, 837-839) and by the tools when no seed is given.
 class Rng {
 public:
     Rng(const uint32_t* seed_words, int count, uint64_t stream = 0);
     explicit Rng(uint64_t seed) : Rng(nullptr, 0, seed) {}
+    static Rng secure();  // throws std::runtime_error when the kernel gives no entropy
     uint64_t next();
     Torus32 uniform_torus32() { return (Torus32)(uint32_t)(next() >> 32); }
     int32_t bit() { return (int32_t)(next() >> 63); }
@@ -26,12 +32,20 @@ public:
     Torus32 gaussian_torus32(double sigma);
 
 private:
+    void chacha_refill();
     uint64_t s_[4];
     bool have_spare_ = false;
     double spare_ = 0;
+    bool chacha_ = false;
+    uint32_t key_[8] = {0}, nonce_[3] = {0};
+    uint64_t counter_ = 0;
+    uint64_t buf_[8];
+    int buf_pos_ = 8;
 };
 
 // Full key generation (secret + cloud key).  with_cloud=false skips BK/KSK.
+// nseed >= 0: reproducible from the seed words (keygen.c:30,34 uses fixed ones);
+// nseed < 0: all randomness from Rng::secure().
 void keygen(const Params& p, const uint32_t* seed_words, int nseed, SecretKeyData* out,
             bool with_cloud = true);
 

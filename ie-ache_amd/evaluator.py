@@ -15,7 +15,14 @@ _LIB = None
 
 CIRC_ADD, CIRC_SUB, CIRC_RSUB, CIRC_MUL, CIRC_MULADD = 1, 2, 3, 4, 5
 CIRC_ADD_KS, CIRC_SUB_KS, CIRC_RSUB_KS = 6, 7, 8  # Kogge-Stone variants (decrypt-identical, not bit-identical)
-GATE_AND, GATE_XOR, GATE_OR, GATE_NAND = 0, 1, 2, 3
+GATE_AND, GATE_XOR, GATE_OR, GATE_NAND, GATE_MUX = 0, 1, 2, 3, 4
+
+
+def circ_chain(k1, k2, flip=True):
+    """IEACHE_CIRC_CHAIN: stage 1 = k1(A, B), stage 2 = k2(answer, C) (flip) or k2(C, answer) --
+    compute() followed by compute_final() (Cloud/dragonfly_cipher_cloud.py:1219-1327) as one DAG."""
+    assert 1 <= k1 <= 4 and 1 <= k2 <= 4
+    return 32 + (k1 - 1) + 4 * (k2 - 1) + (0 if flip else 16)
 
 
 class IeacheError(RuntimeError):
@@ -59,7 +66,7 @@ class Stats(C.Structure):
 class CircuitInfo(C.Structure):
     _fields_ = [("n_inputs", C.c_int32), ("n_outputs", C.c_int32), ("n_slots", C.c_int32), ("depth", C.c_int32),
                 ("max_width", C.c_int32), ("bootstraps", C.c_int64), ("n_and", C.c_int64), ("n_xor", C.c_int64),
-                ("sched_max_width", C.c_int32), ("reserved", C.c_int32)]
+                ("sched_max_width", C.c_int32), ("folded", C.c_int32), ("reference_bootstraps", C.c_int64)]
 
 
 def library_path():
@@ -94,6 +101,7 @@ def lib():
     pp, sp = C.POINTER(Params), C.POINTER(Stats)
     L.ieache_version.restype = C.c_char_p
     L.ieache_last_error.restype = C.c_char_p
+    L.ieache_last_key_layout.restype = C.c_char_p
     L.ieache_default_params.argtypes = [pp]
     L.ieache_cloud_run.argtypes = [C.c_char_p]
     L.ieache_ctx_create.restype = vp
@@ -114,7 +122,12 @@ def lib():
     L.ieache_ctx_kernel_variant.restype = C.c_char_p
     L.ieache_ctx_kernel_variant.argtypes = [vp]
     L.ieache_circuit_info_get.argtypes = [C.c_int, C.c_int, C.POINTER(CircuitInfo)]
+    L.ieache_circuit_info_get_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(CircuitInfo)]
     L.ieache_circuit_simulate.argtypes = [C.c_int, C.c_int, u8p, u8p]
+    L.ieache_circuit_simulate_ex.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p]
+    L.ieache_ctx_wait_stream.argtypes = [vp, vp]
+    L.ieache_mux_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, sp]
+    L.ieache_mux.argtypes = [vp, C.c_size_t, i32p, i32p, i32p, i32p, sp]
     L.ieache_eval_batch.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, i32p, i32p, sp]
     L.ieache_eval_batch_device.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, vp, sp]
     L.ieache_gates_device.argtypes = [vp, C.c_int, C.c_size_t, vp, vp, vp, sp]
@@ -164,20 +177,20 @@ def device_count():
     return lib().ieache_device_count()
 
 
-def circuit_info(kind, bits):
+def circuit_info(kind, bits, fold=False):
     info = CircuitInfo()
-    check(lib().ieache_circuit_info_get(kind, bits, C.byref(info)))
+    check(lib().ieache_circuit_info_get_ex(kind, bits, int(fold), C.byref(info)))
     return info
 
 
-def circuit_simulate(kind, bits, in_bits):
+def circuit_simulate(kind, bits, in_bits, fold=False):
     """Plaintext run of the levelised, slot-allocated circuit (host only)."""
-    info = circuit_info(kind, bits)
+    info = circuit_info(kind, bits, fold)
     in_bits = np.ascontiguousarray(in_bits, dtype=np.uint8)
     assert in_bits.shape == (info.n_inputs,)
     out = np.zeros(info.n_outputs, dtype=np.uint8)
-    check(lib().ieache_circuit_simulate(kind, bits, in_bits.ctypes.data_as(C.POINTER(C.c_uint8)),
-                                        out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    check(lib().ieache_circuit_simulate_ex(kind, bits, int(fold), in_bits.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                           out.ctypes.data_as(C.POINTER(C.c_uint8))))
     return out
 
 
@@ -236,8 +249,14 @@ class Context:
         check(lib().ieache_ctx_set_chunk(self.h, items))
 
     def set_option(self, name, value):
-        """Tuning knobs: chunk, force_generic, ks_batch_min, br_slice."""
+        """Tuning knobs: chunk, force_generic, ks_batch_min, br_slice, ..., fold_constants."""
         check(lib().ieache_ctx_set_option(self.h, name.encode(), int(value)))
+        if name == "fold_constants":
+            self._fold = bool(value)
+
+    def wait_stream(self, hip_stream=None):
+        """Order the context's stream after the work queued on `hip_stream` (int handle; None = default stream)."""
+        check(lib().ieache_ctx_wait_stream(self.h, C.c_void_p(hip_stream)))
 
     def force_generic(self, on=True):
         check(lib().ieache_ctx_force_generic(self.h, int(on)))
@@ -247,7 +266,7 @@ class Context:
 
     def eval_batch(self, kind, bits, in_lwe, stats=None):
         """in_lwe [batch][n_inputs][n+1] int32 on the host -> [batch][n_outputs][n+1]."""
-        info = circuit_info(kind, bits)
+        info = circuit_info(kind, bits, getattr(self, "_fold", False))
         in_lwe = np.ascontiguousarray(in_lwe, dtype=np.int32)
         batch = in_lwe.shape[0]
         assert in_lwe.shape == (batch, info.n_inputs, self.params.n + 1), in_lwe.shape
@@ -274,6 +293,19 @@ class Context:
     def gates_device(self, gate_type, count, d_a, d_b, d_out, stats=None):
         check(lib().ieache_gates_device(self.h, gate_type, count, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out),
                                         C.byref(stats) if stats is not None else None))
+
+    def mux(self, a, b, c, stats=None):
+        """bootsMUX on host rows: out[i] = a[i] ? b[i] : c[i]."""
+        a, b, c = (np.ascontiguousarray(v, dtype=np.int32) for v in (a, b, c))
+        assert a.shape == b.shape == c.shape and a.shape[-1] == self.params.n + 1
+        out = np.zeros_like(a)
+        check(lib().ieache_mux(self.h, a.size // (self.params.n + 1), _i32(a), _i32(b), _i32(c), _i32(out),
+                               C.byref(stats) if stats is not None else None))
+        return out
+
+    def mux_device(self, count, d_a, d_b, d_c, d_out, stats=None):
+        check(lib().ieache_mux_device(self.h, count, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_c), C.c_void_p(d_out),
+                                      C.byref(stats) if stats is not None else None))
 
     def debug_blind_rotate(self, x, steps=-1):
         x = np.ascontiguousarray(x, dtype=np.int32).reshape(-1, self.params.n + 1)

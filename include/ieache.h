@@ -9,6 +9,15 @@
  * ieache_last_error() holds the message.  A context is not thread-safe; use one
  * per process per GPU.
  *
+ * Streams: a context launches on its own non-blocking HIP stream
+ * (ieache_ctx_stream).  Every entry point that takes DEVICE pointers
+ * (ieache_ctx_create_device, ieache_eval_batch_device, ieache_gates_device,
+ * ieache_mux_device) reads them on that stream without ordering against the
+ * stream that produced them: the caller must either have synchronised the
+ * producing stream (torch.cuda.synchronize(), hipStreamSynchronize) or call
+ * ieache_ctx_wait_stream(ctx, producer) first.  Outputs are complete when the
+ * call returns (each call synchronises the context's stream before returning).
+ *
  * Sample layout: one LWE sample = int32[n+1] = a[0..n-1], b (Torus32).  Host
  * buffers are packed rows of n+1; DEVICE buffers are rows of
  * ieache_lwe_stride() int32 (n+1 rounded up to a multiple of 4).
@@ -60,13 +69,26 @@ typedef struct ieache_stats {
 #define IEACHE_CIRC_SUB_KS 7   /* result, depth 2*log2(bits)+2 instead of 3*bits, not the same       */
 #define IEACHE_CIRC_RSUB_KS 8  /* ciphertext bits as the reference's ripple adders                   */
 #define IEACHE_CIRC_MULADD 5  /* (A*B)+C, the compute_final() chaining of
-                                 Cloud/dragonfly_cipher_cloud.py:1300-1327 fused (64-bit A,B) */
+                                 Cloud/dragonfly_cipher_cloud.py:1300-1327 fused; 32-, 64- or 128-bit A,B
+                                 (= IEACHE_CIRC_CHAIN(MUL, ADD, 1)) */
+/* Any two operators chained as compute() + compute_final() do
+ * (dragonfly_cipher_cloud.py:1219-1327), fused into one DAG without the answer.data
+ * round trip: stage 1 = k1(A, B); stage 2 = k2(answer, C) when flip (cloud.data =
+ * answer | C, :1306-1314) or k2(C, answer) otherwise (:1318-1326).  k1, k2 in
+ * {ADD, SUB, RSUB, MUL}.  Inputs per expression: A bits, B bits, A's 32-sample carry
+ * word, C at stage 2's width (bits, or 2*bits after a MUL) [, C's carry word when
+ * !flip].  E.g. the paper's A+B-C = IEACHE_CIRC_CHAIN(ADD, SUB, 1), A*B*C =
+ * IEACHE_CIRC_CHAIN(MUL, MUL, 1) (AC058.pdf Fig. 7). */
+#define IEACHE_CIRC_CHAIN(k1, k2, flip) (32 + ((k1)-1) + 4 * ((k2)-1) + ((flip) ? 0 : 16))
 
 /* gate types = libtfhe boot-gates.cpp entry points used by cloud.c:30-43,159 */
 #define IEACHE_GATE_AND 0
 #define IEACHE_GATE_XOR 1
 #define IEACHE_GATE_OR 2
 #define IEACHE_GATE_NAND 3
+/* three-input gate, own entry points (ieache_mux*): bootsMUX(a,b,c) = a ? b : c.
+ * Not called by Cloud/cloud.c; BASELINE.json's north_star names it. */
+#define IEACHE_GATE_MUX 4
 
 typedef struct ieache_circuit_info {
     int32_t n_inputs;    /* samples per expression: A bits, B bits, 32-sample carry word [, C bits] */
@@ -76,11 +98,17 @@ typedef struct ieache_circuit_info {
     int32_t max_width;   /* widest ASAP level */
     int64_t bootstraps, n_and, n_xor;
     int32_t sched_max_width; /* widest level of the slack-balanced schedule the executor runs */
-    int32_t reserved;
+    int32_t folded;          /* 1 when this is the constant-folded variant (see "fold_constants") */
+    int64_t reference_bootstraps; /* gates Cloud/cloud.c performs for this circuit; == bootstraps unless folded */
 } ieache_circuit_info;
 
 const char* ieache_version(void);
 const char* ieache_last_error(void);
+/* Key files are libtfhe's tfhe_io.cpp serialisations; libtfhe is not in the reference tree, so the
+ * reader locates text sections by title and picks the binary layout among enumerated hypotheses
+ * by the exact byte count (csrc/codec.h).  This names the hypothesis the calling thread's last
+ * key load matched. */
+const char* ieache_last_key_layout(void);
 int ieache_device_count(void);
 
 /* ------------------------------------------------------------------ *
@@ -112,13 +140,20 @@ int ieache_ctx_params(const ieache_ctx* ctx, ieache_params* out);
 int ieache_lwe_stride(const ieache_ctx* ctx);
 /* the HIP stream the evaluator launches on (hipStream_t as void*) */
 void* ieache_ctx_stream(const ieache_ctx* ctx);
+/* make the context's stream wait for the work queued so far on `hip_stream`
+ * (hipStream_t as void*; NULL = the default stream) -- see "Streams" above */
+int ieache_ctx_wait_stream(ieache_ctx* ctx, void* hip_stream);
 /* same contract as ieache_cloud_run but with this context's resident key */
 int ieache_ctx_cloud_run(ieache_ctx* ctx, const char* workdir);
 /* tuning / test knobs */
 int ieache_ctx_set_chunk(ieache_ctx* ctx, int64_t gate_instances_per_launch);
 int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
 /* named knobs: "chunk", "force_generic", "ks_sliced_min", "ks_gates", "ks_slice", "ks_batch_min",
- * "br_slice", "br_wide_max", "br_variant" (see csrc/evaluator.h) */
+ * "br_slice", "br_wide_max", "br_variant" (see csrc/evaluator.h), and
+ * "fold_constants" (0/1, default 0, also IEACHE_FOLD=1 for the process contract): build circuits
+ * with constant operands folded and repeated gates shared.  cloud.c bootstraps every gate, even
+ * `x AND 0` on the zero rows of its shift-add multipliers (SURVEY App. C note); the folded circuit
+ * decrypts to the same bits with fewer bootstraps but is NOT the reference's ciphertext. */
 int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value);
 const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx);
 
@@ -127,9 +162,11 @@ const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx);
  *    circuit, level by level.  Replaces the add()/mul32()/mul64()/    *
  *    mul128()/split() call trees of cloud.c:18-647 and their use in   *
  *    main().  bits: 16 (generalised add(...,16,...)), 32, 64, 128,    *
- *    256 for ADD/SUB/RSUB; 32/64/128 for MUL; 64 for MULADD.          *
+ *    256 for ADD/SUB/RSUB; 32/64/128 for MUL and MULADD; chains: see  *
+ *    IEACHE_CIRC_CHAIN.                                               *
  * ------------------------------------------------------------------ */
 int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out);
+int ieache_circuit_info_get_ex(int kind, int bits, int fold_constants, ieache_circuit_info* out);
 /* host buffers: in [batch][n_inputs][n+1], out [batch][n_outputs][n+1] */
 int ieache_eval_batch(ieache_ctx* ctx, int kind, int bits, size_t batch, const int32_t* in_lwe, int32_t* out_lwe,
                       ieache_stats* stats);
@@ -143,8 +180,16 @@ int ieache_gates_device(ieache_ctx* ctx, int gate_type, size_t count, const int3
 /* host rows of n+1 */
 int ieache_gates(ieache_ctx* ctx, int gate_type, size_t count, const int32_t* a, const int32_t* b, int32_t* out,
                  ieache_stats* stats);
+/* out[i] = a[i] ? b[i] : c[i]; replaces bootsMUX (libtfhe boot-gates.cpp): per gate two blind
+ * rotations without key switch, their extracted samples added to (0, 1/8), one key switch.
+ * stats->bootstraps counts the blind rotations (2 per gate). */
+int ieache_mux_device(ieache_ctx* ctx, size_t count, const int32_t* d_a, const int32_t* d_b, const int32_t* d_c,
+                      int32_t* d_out, ieache_stats* stats);
+int ieache_mux(ieache_ctx* ctx, size_t count, const int32_t* a, const int32_t* b, const int32_t* c, int32_t* out,
+               ieache_stats* stats);
 /* plaintext simulation of the levelised circuit (host only, no GPU): bits in/out 0/1 */
 int ieache_circuit_simulate(int kind, int bits, const uint8_t* in_bits, uint8_t* out_bits);
+int ieache_circuit_simulate_ex(int kind, int bits, int fold_constants, const uint8_t* in_bits, uint8_t* out_bits);
 
 /* stage hooks for parity tests (host rows): blind rotation from the
  * test-vector after `steps` CMux steps (<0: all n) -> acc [count][2][N];
@@ -157,11 +202,17 @@ int ieache_debug_keyswitch(ieache_ctx* ctx, size_t count, const int32_t* u, int3
  *    Client1/alice.c:116-191 and Output/verif.c:41-76 get from        *
  *    libtfhe.  Needed to produce and check ciphertexts without it.    *
  * ------------------------------------------------------------------ */
+/* Randomness: a seed / seed-word list gives a REPRODUCIBLE xoshiro256** stream -- for test
+ * vectors and for mirroring keygen.c's fixed seeds, not cryptographic (the generator's raw
+ * outputs are published as the `a` coefficients).  seed == 0 (encrypt_bits, alice) or
+ * n_seed_words < 0 (keygen) draws everything from a ChaCha20 stream keyed by getrandom(2).
+ * The fresh metadata encryptions of the process contract always use the latter. */
 /* raw key material; any output pointer may be NULL to skip it */
 int ieache_keygen_raw(const ieache_params* p, const uint32_t* seed_words, int n_seed_words, int32_t* lwe_key /*[n]*/,
                       int32_t* tlwe_key /*[kN]*/, int32_t* bk, int32_t* ksk);
 /* keygen.c equivalent: writes secret.key, cloud.key, nbit.key into `dir`
- * (seeds {314,1592,657} / {314,1592,888} as keygen.c:30,34 when seeds are NULL) */
+ * (seeds {314,1592,657} / {314,1592,888} as keygen.c:30,34 when seeds are NULL and the
+ * counts are >= 0; a count < 0 = kernel entropy for that key set) */
 int ieache_keygen_files(const char* dir, const ieache_params* p, const uint32_t* seed, int n_seed,
                         const uint32_t* nbit_seed, int n_nbit_seed);
 /* bootsSymEncrypt / bootsSymDecrypt over arrays of bits; rows of n+1 */

@@ -32,9 +32,9 @@ void orc_add(const orc_cloudkey *ck, int32_t *sum, int32_t *carryover, const int
         orc_gate_xor(ck, carry, carry, axc);           /* :43 */
     }
     orc_gate_copy(ck, carryover, carry); /* :46 carry-out to carryover[0] only */
-    free(carry);
-    free(axc);
-    free(bxc);
+    orc_scratch_free(ck, carry);
+    orc_scratch_free(ck, axc);
+    orc_scratch_free(ck, bxc);
 }
 
 /* cloud.c:53-57 */
@@ -73,12 +73,12 @@ void orc_split(const orc_cloudkey *ck, int32_t *f1, int32_t *f2, int32_t *f3, co
     copy_bits(ck, f1, sum3, nb_bits);             /* :94-105 */
     copy_bits(ck, f2, sum2, nb_bits);
     copy_bits(ck, f3, sum, nb_bits);
-    free(sum);
-    free(sum2);
-    free(sum3);
-    free(co);
-    free(co2);
-    free(co3);
+    orc_scratch_free(ck, sum);
+    orc_scratch_free(ck, sum2);
+    orc_scratch_free(ck, sum3);
+    orc_scratch_free(ck, co);
+    orc_scratch_free(ck, co2);
+    orc_scratch_free(ck, co3);
 }
 
 /* Shared body of mul32/mul64/mul128 (cloud.c:115-218, 220-385, 387-647):
@@ -130,11 +130,11 @@ static void mul_generic(const orc_cloudkey *ck, int32_t **results /*[words+1], h
     }
     for (int w = 0; w < W1; w++) copy_bits(ck, results[w], sum[W1 - 1 - w], 32); /* :200-204 */
     for (int w = 0; w < W1; w++) {
-        free(sum[w]);
-        free(t3c[w]);
-        free(cy[w]);
+        orc_scratch_free(ck, sum[w]);
+        orc_scratch_free(ck, t3c[w]);
+        orc_scratch_free(ck, cy[w]);
     }
-    for (int w = 0; w < words; w++) free(tmp[w]);
+    for (int w = 0; w < words; w++) orc_scratch_free(ck, tmp[w]);
 }
 
 /* cloud.c:115-218 : result = high word, result2 = low word */
@@ -215,10 +215,10 @@ int orc_cloud_values(const orc_cloudkey *ck, int32_t op, int32_t neg, int32_t in
         for (int w = 0; w < W; w++) {
             int32_t *cy = new_array(ck, 32);
             orc_add(ck, outw[w], cy, opnd1 + w * word, opnd2 + w * word, w == 0 ? carry1 : cy_prev, 32);
-            free(cy_prev);
+            orc_scratch_free(ck, cy_prev);
             cy_prev = cy;
         }
-        free(cy_prev);
+        orc_scratch_free(ck, cy_prev);
         nwords_out = W;
     } else if (is_sub) {
         /* :1196 A-B / A+(-B): complement operand 2, add to operand 1.
@@ -240,31 +240,31 @@ int orc_cloud_values(const orc_cloudkey *ck, int32_t op, int32_t neg, int32_t in
                 orc_add(ck, twos[0], twoscarry[0], inverse, temp, tempcarry, 32); /* :1236 */
             else
                 orc_add(ck, twos[w], twoscarry[w], inverse, tempcarry, twoscarry[w - 1], 32); /* :1341 */
-            free(inverse);
-            free(tempcarry);
+            orc_scratch_free(ck, inverse);
+            orc_scratch_free(ck, tempcarry);
         }
         int32_t *cy_prev = NULL;
         for (int w = 0; w < W; w++) { /* :1245, :1352-1353 */
             int32_t *cy = new_array(ck, 32);
             orc_add(ck, outw[w], cy, keep + w * word, twos[w], w == 0 ? carry1 : cy_prev, 32);
-            free(cy_prev);
+            orc_scratch_free(ck, cy_prev);
             cy_prev = cy;
         }
-        free(cy_prev);
+        orc_scratch_free(ck, cy_prev);
         for (int w = 0; w < W; w++) {
-            free(twos[w]);
-            free(twoscarry[w]);
+            orc_scratch_free(ck, twos[w]);
+            orc_scratch_free(ck, twoscarry[w]);
         }
-        free(temp);
+        orc_scratch_free(ck, temp);
         nwords_out = W;
     } else if (op == 4) {
         if (int_bit == 32) { /* :2655-2718 */
             int32_t *r1 = new_array(ck, 32), *r2 = new_array(ck, 32);
             orc_mul32(ck, r1, r2, opnd1, opnd2, carry1, 32);
-            memcpy(outw[0], r2, word * sizeof(int32_t)); /* low first :2683-2686 */
-            memcpy(outw[1], r1, word * sizeof(int32_t));
-            free(r1);
-            free(r2);
+            copy_bits(ck, outw[0], r2, 32); /* low first :2683-2686 */
+            copy_bits(ck, outw[1], r1, 32);
+            orc_scratch_free(ck, r1);
+            orc_scratch_free(ck, r2);
             nwords_out = 2;
         } else if (int_bit == 64) { /* :2568-2654 */
             int32_t *r[6], *f[3];
@@ -273,12 +273,12 @@ int orc_cloud_values(const orc_cloudkey *ck, int32_t op, int32_t neg, int32_t in
             orc_mul64(ck, r[0], r[1], r[2], opnd1, opnd1 + word, opnd2, carry1, 32);        /* :2589 */
             orc_mul64(ck, r[3], r[4], r[5], opnd1, opnd1 + word, opnd2 + word, carry1, 32); /* :2592 */
             orc_split(ck, f[0], f[1], f[2], r[0], r[1], r[3], r[4], r[5], carry1, 32);      /* :2594 */
-            memcpy(outw[0], r[2], word * sizeof(int32_t)); /* :2609-2616 */
-            memcpy(outw[1], f[2], word * sizeof(int32_t));
-            memcpy(outw[2], f[1], word * sizeof(int32_t));
-            memcpy(outw[3], f[0], word * sizeof(int32_t));
-            for (int q = 0; q < 6; q++) free(r[q]);
-            for (int q = 0; q < 3; q++) free(f[q]);
+            copy_bits(ck, outw[0], r[2], 32); /* :2609-2616 */
+            copy_bits(ck, outw[1], f[2], 32);
+            copy_bits(ck, outw[2], f[1], 32);
+            copy_bits(ck, outw[3], f[0], 32);
+            for (int q = 0; q < 6; q++) orc_scratch_free(ck, r[q]);
+            for (int q = 0; q < 3; q++) orc_scratch_free(ck, f[q]);
             nwords_out = 4;
         } else if (int_bit == 128) { /* :2371-2567 */
             int32_t *r[21], *sm[16], *co[16];
@@ -307,11 +307,11 @@ int orc_cloud_values(const orc_cloudkey *ck, int32_t op, int32_t neg, int32_t in
             orc_add(ck, sm[14], co[14], sm[10], r[17], co[13], 32);
             orc_add(ck, sm[15], co[15], r[16], carry1, co[14], 32);
             const int32_t *ex[8] = {r[5], sm[1], sm[6], sm[11], sm[12], sm[13], sm[14], sm[15]}; /* :2476-2491 */
-            for (int q = 0; q < 8; q++) memcpy(outw[q], ex[q], word * sizeof(int32_t));
-            for (int q = 1; q <= 20; q++) free(r[q]);
+            for (int q = 0; q < 8; q++) copy_bits(ck, outw[q], ex[q], 32);
+            for (int q = 1; q <= 20; q++) orc_scratch_free(ck, r[q]);
             for (int q = 1; q <= 15; q++) {
-                free(sm[q]);
-                free(co[q]);
+                orc_scratch_free(ck, sm[q]);
+                orc_scratch_free(ck, co[q]);
             }
             nwords_out = 8;
         } else
@@ -319,6 +319,6 @@ int orc_cloud_values(const orc_cloudkey *ck, int32_t op, int32_t neg, int32_t in
     } else
         return -1;
     /* unused words + the trailing carry word are operand 1's carry word (e.g. :901-916) */
-    for (int w = nwords_out; w < 9; w++) memcpy(outw[w], carry1, word * sizeof(int32_t));
+    for (int w = nwords_out; w < 9; w++) copy_bits(ck, outw[w], carry1, 32);
     return 0;
 }

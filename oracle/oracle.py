@@ -64,6 +64,13 @@ def lib():
         L.orc_mul32.argtypes = [vp] + [i32p] * 5 + [C.c_int32]
         L.orc_cloud_values.restype = C.c_int
         L.orc_cloud_values.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, i32p, i32p]
+        L.orc_gate_mux.argtypes = [vp, i32p, i32p, i32p, i32p]
+        L.orc_bootstrap_woks.argtypes = [vp, i32p, i32p]
+        L.orc_defer_begin.argtypes = [vp]
+        L.orc_defer_run.restype = C.c_int64
+        L.orc_defer_run.argtypes = [vp, C.c_int]
+        L.orc_gates_batch.argtypes = [vp, C.c_int32, C.c_size_t, i32p, i32p, i32p, C.c_int]
+        L.orc_max_threads.restype = C.c_int
         L.orc_cloud_metadata.restype = C.c_int
         L.orc_cloud_metadata.argtypes = [C.c_int32] * 5 + [i32p] * 4
         _LIB = L
@@ -180,6 +187,27 @@ class CloudKey:
             f(self.h, _p(out), _p(ca), _p(cb))
         return out
 
+    def mux(self, a, b, c):
+        """bootsMUX(a, b, c) = a ? b : c."""
+        a, b, c = (np.ascontiguousarray(v, dtype=np.int32) for v in (a, b, c))
+        out = self._new()
+        lib().orc_gate_mux(self.h, _p(out), _p(a), _p(b), _p(c))
+        return out
+
+    def bootstrap_woks(self, x):
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        u = np.zeros(self.k * self.N + 1, dtype=np.int32)
+        lib().orc_bootstrap_woks(self.h, _p(u), _p(x))
+        return u
+
+    def gates_batch(self, name, a, b, threads=0):
+        """`count` independent gates on `threads` host threads (0 = all): out[i] = gate(a[i], b[i])."""
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        b = np.ascontiguousarray(b, dtype=np.int32)
+        out = np.zeros_like(a)
+        lib().orc_gates_batch(self.h, {"and": 0, "xor": 1, "or": 2, "nand": 3}[name], a.shape[0], _p(out), _p(a), _p(b), threads)
+        return out
+
     # --- circuits ---
     def add(self, x, y, c, nb_bits):
         """cloud.c add(): returns (sum[nb_bits], carryover[1])."""
@@ -200,15 +228,20 @@ class CloudKey:
         lib().orc_mul32(self.h, _p(hi), _p(lo), _p(a), _p(b), _p(carry), 32)
         return hi, lo
 
-    def cloud_values(self, op, neg, int_bit, opnd1, opnd2, carry1):
+    def cloud_values(self, op, neg, int_bit, opnd1, opnd2, carry1, threads=1):
         """Value part of cloud.c main(): operands [8][32][n+1], carry1 [32][n+1]
-        -> (rc, out [9][32][n+1])."""
+        -> (rc, out [9][32][n+1]).  threads != 1: the same sequential gate stream is recorded and
+        its independent gates evaluated on that many host threads (0 = all); identical bits."""
         opnd1 = np.ascontiguousarray(opnd1, dtype=np.int32)
         opnd2 = np.ascontiguousarray(opnd2, dtype=np.int32)
         carry1 = np.ascontiguousarray(carry1, dtype=np.int32)
         assert opnd1.shape == (8, 32, self.n + 1) and carry1.shape == (32, self.n + 1)
         out = np.zeros((9, 32, self.n + 1), dtype=np.int32)
+        if threads != 1:
+            lib().orc_defer_begin(self.h)
         rc = lib().orc_cloud_values(self.h, op, neg, int_bit, _p(opnd1), _p(opnd2), _p(carry1), _p(out))
+        if threads != 1:
+            lib().orc_defer_run(self.h, threads)
         return rc, out
 
 
@@ -217,6 +250,10 @@ def cloud_metadata(op, neg1, bit1, neg2, bit2):
     vals = [C.c_int32() for _ in range(4)]
     rc = lib().orc_cloud_metadata(op, neg1, bit1, neg2, bit2, *[C.byref(v) for v in vals])
     return (rc,) + tuple(v.value for v in vals)
+
+
+def max_threads():
+    return lib().orc_max_threads()
 
 
 def lwe_phase(sample, key):

@@ -11,6 +11,9 @@
  */
 #define _GNU_SOURCE
 #include "tfhe_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -253,6 +256,7 @@ struct orc_cloudkey {
     fft_plan fft;
     double *bk_fft;   /* [n][(k+1)l][k+1][2][M] */
     uint64_t nboot;
+    struct orc_trace *trace; /* non-NULL while gates are being recorded (orc_defer_begin) */
 };
 
 static size_t bk_count(const orc_params *p)
@@ -574,26 +578,263 @@ void orc_bootstrap(const orc_cloudkey *ck, int32_t *out, const int32_t *x)
     orc_blind_rotate(ck, acc, bara);
     orc_sample_extract(ck, u, acc);
     orc_keyswitch(ck, out, u);
-    ((orc_cloudkey *)ck)->nboot++;
+    __atomic_fetch_add(&((orc_cloudkey *)ck)->nboot, 1, __ATOMIC_RELAXED);
     free(bara);
     free(acc);
     free(u);
 }
 
+/* ---- deferred evaluation -------------------------------------------------
+ * The circuits of cloud_oracle.c issue their gates strictly one after the
+ * other, as the reference does.  Between orc_defer_begin() and
+ * orc_defer_run() the gate functions only RECORD what they were asked to do
+ * (type, destination, operands, by address); orc_defer_run() then renames
+ * every write (so reuse of a scratch sample creates no false dependency),
+ * levelises the recorded gates and evaluates each level's independent gates
+ * on several threads.  Every gate is still computed by exactly the code
+ * below from exactly the operand values the sequential run would have used,
+ * so the results are identical; only the wall time changes (golden vectors
+ * at n = 630, all-cores cpu_baseline). */
+enum { OP_AND, OP_XOR, OP_OR, OP_NAND, OP_NOT, OP_COPY, OP_CONST0, OP_CONST1, OP_MUX };
+typedef struct {
+    int32_t type;
+    int32_t dep[3]; /* producing op of each operand, or -1: read the caller's memory */
+    int32_t *dst;
+    const int32_t *src[3];
+    int32_t level;
+} orc_op;
+struct orc_trace {
+    orc_op *ops;
+    size_t n_ops, cap_ops;
+    /* open-addressing map: sample address -> index of the op that last wrote it */
+    const int32_t **keys;
+    int32_t *vals;
+    size_t map_cap, map_used;
+    void **deferred_free;
+    size_t n_free, cap_free;
+};
+
+static size_t trace_slot(const struct orc_trace *t, const int32_t *key)
+{
+    size_t h = ((uintptr_t)key >> 2) * (size_t)0x9E3779B97F4A7C15ULL;
+    h ^= h >> 29;
+    size_t i = h & (t->map_cap - 1);
+    while (t->keys[i] && t->keys[i] != key) i = (i + 1) & (t->map_cap - 1);
+    return i;
+}
+static void trace_grow(struct orc_trace *t)
+{
+    size_t old_cap = t->map_cap;
+    const int32_t **ok = t->keys;
+    int32_t *ov = t->vals;
+    t->map_cap = old_cap ? old_cap * 2 : 1 << 16;
+    t->keys = (const int32_t **)calloc(t->map_cap, sizeof(*t->keys));
+    t->vals = (int32_t *)malloc(t->map_cap * sizeof(*t->vals));
+    for (size_t i = 0; i < old_cap; i++)
+        if (ok[i]) {
+            size_t s = trace_slot(t, ok[i]);
+            t->keys[s] = ok[i];
+            t->vals[s] = ov[i];
+        }
+    free(ok);
+    free(ov);
+}
+static int32_t trace_lookup(const struct orc_trace *t, const int32_t *key)
+{
+    if (!t->map_cap) return -1;
+    size_t s = trace_slot(t, key);
+    return t->keys[s] ? t->vals[s] : -1;
+}
+static void trace_record(const orc_cloudkey *ck, int32_t type, int32_t *dst, const int32_t *a,
+                         const int32_t *b, const int32_t *c)
+{
+    struct orc_trace *t = ck->trace;
+    if (t->n_ops == t->cap_ops) {
+        t->cap_ops = t->cap_ops ? t->cap_ops * 2 : 4096;
+        t->ops = (orc_op *)realloc(t->ops, t->cap_ops * sizeof(orc_op));
+    }
+    orc_op *op = &t->ops[t->n_ops];
+    op->type = type;
+    op->dst = dst;
+    op->src[0] = a;
+    op->src[1] = b;
+    op->src[2] = c;
+    op->level = 0;
+    for (int q = 0; q < 3; q++) op->dep[q] = op->src[q] ? trace_lookup(t, op->src[q]) : -1;
+    if ((t->map_used + 1) * 2 > t->map_cap) trace_grow(t);
+    size_t s = trace_slot(t, dst);
+    if (!t->keys[s]) {
+        t->keys[s] = dst;
+        t->map_used++;
+    }
+    t->vals[s] = (int32_t)t->n_ops;
+    t->n_ops++;
+}
+
+void orc_defer_begin(orc_cloudkey *ck)
+{
+    if (ck->trace) return;
+    ck->trace = (struct orc_trace *)calloc(1, sizeof(struct orc_trace));
+}
+
+/* cloud_oracle.c releases its scratch arrays through this: while gates are being
+ * recorded the memory must stay (recorded operands are addresses) */
+void orc_scratch_free(const orc_cloudkey *ck, void *p)
+{
+    if (!p) return;
+    struct orc_trace *t = ck->trace;
+    if (!t) {
+        free(p);
+        return;
+    }
+    if (t->n_free == t->cap_free) {
+        t->cap_free = t->cap_free ? t->cap_free * 2 : 256;
+        t->deferred_free = (void **)realloc(t->deferred_free, t->cap_free * sizeof(void *));
+    }
+    t->deferred_free[t->n_free++] = p;
+}
+
+static void gate2(const orc_cloudkey *ck, int32_t *out, int32_t cst, int32_t sa, const int32_t *ca,
+                  int32_t sb, const int32_t *cb);
+static void mux_now(const orc_cloudkey *ck, int32_t *out, const int32_t *a, const int32_t *b,
+                    const int32_t *c);
+
+static void run_op(const orc_cloudkey *ck, int32_t type, int32_t *out, const int32_t *a,
+                   const int32_t *b, const int32_t *c)
+{
+    const int32_t n = ck->p.n, MU = orc_modswitch_to_torus32(1, 8);
+    switch (type) {
+    case OP_AND: gate2(ck, out, orc_modswitch_to_torus32(-1, 8), 1, a, 1, b); break;
+    case OP_XOR: gate2(ck, out, orc_modswitch_to_torus32(1, 4), 2, a, 2, b); break;
+    case OP_OR: gate2(ck, out, orc_modswitch_to_torus32(1, 8), 1, a, 1, b); break;
+    case OP_NAND: gate2(ck, out, orc_modswitch_to_torus32(1, 8), -1, a, -1, b); break;
+    case OP_NOT:
+        for (int32_t j = 0; j <= n; j++) out[j] = (int32_t)(0u - (uint32_t)a[j]);
+        break;
+    case OP_COPY:
+        if (out != a) memmove(out, a, sizeof(int32_t) * (n + 1));
+        break;
+    case OP_CONST0:
+    case OP_CONST1:
+        memset(out, 0, sizeof(int32_t) * n);
+        out[n] = type == OP_CONST1 ? MU : (int32_t)(0u - (uint32_t)MU);
+        break;
+    default: mux_now(ck, out, a, b, c); break;
+    }
+}
+
+/* Evaluates everything recorded since orc_defer_begin() on `nthreads` threads (<= 0: all
+ * the host's), stores every sample where the sequential run would have left it, and
+ * leaves deferred mode.  Returns the number of levels of bootstrapped gates it ran. */
+int64_t orc_defer_run(orc_cloudkey *ck, int nthreads)
+{
+    struct orc_trace *t = ck->trace;
+    if (!t) return 0;
+    ck->trace = NULL; /* the gates below compute */
+    const size_t S = (size_t)ck->p.n + 1;
+    int32_t max_level = 0;
+    for (size_t i = 0; i < t->n_ops; i++) {
+        orc_op *op = &t->ops[i];
+        int32_t lv = 0;
+        for (int q = 0; q < 3; q++)
+            if (op->dep[q] >= 0 && t->ops[op->dep[q]].level > lv) lv = t->ops[op->dep[q]].level;
+        const int boots = op->type <= OP_NAND || op->type == OP_MUX;
+        op->level = lv + (boots ? 1 : 0); /* free gates ride in their producer's level */
+        if (op->level > max_level) max_level = op->level;
+    }
+    /* one value buffer per recorded write (SSA); ops of a level are independent of each other
+     * but a free gate may read a value produced in its own level, so within a level the
+     * bootstrapped gates run first (in parallel), then the free ones in recording order */
+    int32_t *vals = (int32_t *)malloc(t->n_ops * S * sizeof(int32_t));
+    size_t *order = (size_t *)malloc((t->n_ops + 1) * sizeof(size_t));
+    size_t *first = (size_t *)calloc((size_t)max_level + 2, sizeof(size_t));
+    for (size_t i = 0; i < t->n_ops; i++) first[t->ops[i].level + 1]++;
+    for (int32_t l = 0; l <= max_level; l++) first[l + 1] += first[l];
+    {
+        size_t *fill = (size_t *)malloc(((size_t)max_level + 1) * sizeof(size_t));
+        memcpy(fill, first, ((size_t)max_level + 1) * sizeof(size_t));
+        for (size_t i = 0; i < t->n_ops; i++) order[fill[t->ops[i].level]++] = i;
+        free(fill);
+    }
+#define OPERAND(op, q) ((op)->src[q] ? ((op)->dep[q] >= 0 ? vals + (size_t)(op)->dep[q] * S : (op)->src[q]) : NULL)
+    for (int32_t l = 0; l <= max_level; l++) {
+        const size_t lo = first[l], hi = first[l + 1];
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : omp_get_max_threads())
+#endif
+        for (size_t q = lo; q < hi; q++) {
+            const orc_op *op = &t->ops[order[q]];
+            if (!(op->type <= OP_NAND || op->type == OP_MUX)) continue;
+            run_op(ck, op->type, vals + order[q] * S, OPERAND(op, 0), OPERAND(op, 1), OPERAND(op, 2));
+        }
+        for (size_t q = lo; q < hi; q++) {
+            const orc_op *op = &t->ops[order[q]];
+            if (op->type <= OP_NAND || op->type == OP_MUX) continue;
+            run_op(ck, op->type, vals + order[q] * S, OPERAND(op, 0), OPERAND(op, 1), OPERAND(op, 2));
+        }
+    }
+#undef OPERAND
+    /* every address ends up holding its last recorded write */
+    for (size_t i = 0; i < t->map_cap; i++)
+        if (t->keys[i]) memcpy((int32_t *)t->keys[i], vals + (size_t)t->vals[i] * S, S * sizeof(int32_t));
+    for (size_t i = 0; i < t->n_free; i++) free(t->deferred_free[i]);
+    free(vals);
+    free(order);
+    free(first);
+    free(t->ops);
+    free(t->keys);
+    free(t->vals);
+    free(t->deferred_free);
+    free(t);
+    return max_level;
+}
+
+/* `count` independent gates of one type on `nthreads` threads (all-cores cpu_baseline) */
+void orc_gates_batch(const orc_cloudkey *ck, int32_t type, size_t count, int32_t *out, const int32_t *a,
+                     const int32_t *b, int nthreads)
+{
+    const size_t S = (size_t)ck->p.n + 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : omp_get_max_threads())
+#endif
+    for (size_t i = 0; i < count; i++) run_op(ck, type, out + i * S, a + i * S, b + i * S, NULL);
+    (void)nthreads;
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 /* ---- boot-gates.cpp ---- */
 void orc_gate_constant(const orc_cloudkey *ck, int32_t *out, int32_t value)
 {
-    const int32_t n = ck->p.n, MU = orc_modswitch_to_torus32(1, 8);
-    memset(out, 0, sizeof(int32_t) * n);
-    out[n] = value ? MU : (int32_t)(0u - (uint32_t)MU);
+    if (ck->trace) {
+        trace_record(ck, value ? OP_CONST1 : OP_CONST0, out, NULL, NULL, NULL);
+        return;
+    }
+    run_op(ck, value ? OP_CONST1 : OP_CONST0, out, NULL, NULL, NULL);
 }
 void orc_gate_not(const orc_cloudkey *ck, int32_t *out, const int32_t *ca)
 {
-    for (int32_t j = 0; j <= ck->p.n; j++) out[j] = (int32_t)(0u - (uint32_t)ca[j]);
+    if (ck->trace) {
+        trace_record(ck, OP_NOT, out, ca, NULL, NULL);
+        return;
+    }
+    run_op(ck, OP_NOT, out, ca, NULL, NULL);
 }
 void orc_gate_copy(const orc_cloudkey *ck, int32_t *out, const int32_t *ca)
 {
-    if (out != ca) memmove(out, ca, sizeof(int32_t) * (ck->p.n + 1));
+    if (out == ca) return;
+    if (ck->trace) {
+        trace_record(ck, OP_COPY, out, ca, NULL, NULL);
+        return;
+    }
+    run_op(ck, OP_COPY, out, ca, NULL, NULL);
 }
 /* t = (0, cst) + sa*ca + sb*cb, then bootstrap */
 static void gate2(const orc_cloudkey *ck, int32_t *out, int32_t cst, int32_t sa, const int32_t *ca,
@@ -607,21 +848,70 @@ static void gate2(const orc_cloudkey *ck, int32_t *out, int32_t cst, int32_t sa,
     orc_bootstrap(ck, out, t);
     free(t);
 }
-void orc_gate_and(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb)
+#define ORC_GATE2(name, OP)                                                                          \
+    void orc_gate_##name(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb) \
+    {                                                                                                \
+        if (ck->trace) {                                                                             \
+            trace_record(ck, OP, out, ca, cb, NULL);                                                 \
+            return;                                                                                  \
+        }                                                                                            \
+        run_op(ck, OP, out, ca, cb, NULL);                                                           \
+    }
+ORC_GATE2(and, OP_AND)   /* (0,-1/8) + ca + cb */
+ORC_GATE2(xor, OP_XOR)   /* (0, 1/4) + 2(ca + cb) */
+ORC_GATE2(or, OP_OR)     /* (0, 1/8) + ca + cb */
+ORC_GATE2(nand, OP_NAND) /* (0, 1/8) - ca - cb */
+
+/* tfhe_bootstrap_woKS_FFT: bootstrap without the final key switch; u is [kN+1] */
+void orc_bootstrap_woks(const orc_cloudkey *ck, int32_t *u, const int32_t *x)
 {
-    gate2(ck, out, orc_modswitch_to_torus32(-1, 8), 1, ca, 1, cb);
+    const orc_params *p = &ck->p;
+    int32_t *bara = (int32_t *)malloc(sizeof(int32_t) * p->n);
+    int32_t *acc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(p->k + 1) * p->N);
+    const int32_t mu = orc_modswitch_to_torus32(1, 8);
+    int32_t barb = orc_modswitch_sample(ck, x, bara);
+    orc_blind_rotate_init(ck, acc, barb, mu);
+    orc_blind_rotate(ck, acc, bara);
+    orc_sample_extract(ck, u, acc);
+    free(bara);
+    free(acc);
 }
-void orc_gate_xor(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb)
+
+/* boot-gates.cpp bootsMUX(a, b, c) = a ? b : c.  Two bootstraps WITHOUT key switch
+ *   u1 = bootstrap_woKS((0,-1/8) + a + b)      "a AND b"
+ *   u2 = bootstrap_woKS((0,-1/8) - a + c)      "(NOT a) AND c"
+ * then ONE key switch of (0, 1/8) + u1 + u2.  Unused by Cloud/cloud.c;
+ * BASELINE.json's north_star names it. */
+static void mux_now(const orc_cloudkey *ck, int32_t *out, const int32_t *a, const int32_t *b,
+                    const int32_t *c)
 {
-    gate2(ck, out, orc_modswitch_to_torus32(1, 4), 2, ca, 2, cb);
+    const int32_t n = ck->p.n, Nin = ck->p.k * ck->p.N;
+    const uint32_t and_const = (uint32_t)orc_modswitch_to_torus32(-1, 8);
+    int32_t *t = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
+    int32_t *u1 = (int32_t *)malloc(sizeof(int32_t) * (Nin + 1));
+    int32_t *u2 = (int32_t *)malloc(sizeof(int32_t) * (Nin + 1));
+    for (int32_t j = 0; j <= n; j++) t[j] = (int32_t)((uint32_t)a[j] + (uint32_t)b[j]);
+    t[n] = (int32_t)((uint32_t)t[n] + and_const);
+    orc_bootstrap_woks(ck, u1, t);
+    for (int32_t j = 0; j <= n; j++) t[j] = (int32_t)((uint32_t)c[j] - (uint32_t)a[j]);
+    t[n] = (int32_t)((uint32_t)t[n] + and_const);
+    orc_bootstrap_woks(ck, u2, t);
+    for (int32_t j = 0; j <= Nin; j++) u1[j] = (int32_t)((uint32_t)u1[j] + (uint32_t)u2[j]);
+    u1[Nin] = (int32_t)((uint32_t)u1[Nin] + (uint32_t)orc_modswitch_to_torus32(1, 8));
+    orc_keyswitch(ck, out, u1);
+    __atomic_fetch_add(&((orc_cloudkey *)ck)->nboot, 2, __ATOMIC_RELAXED);
+    free(t);
+    free(u1);
+    free(u2);
 }
-void orc_gate_or(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb)
+void orc_gate_mux(const orc_cloudkey *ck, int32_t *out, const int32_t *a, const int32_t *b,
+                  const int32_t *c)
 {
-    gate2(ck, out, orc_modswitch_to_torus32(1, 8), 1, ca, 1, cb);
-}
-void orc_gate_nand(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb)
-{
-    gate2(ck, out, orc_modswitch_to_torus32(1, 8), -1, ca, -1, cb);
+    if (ck->trace) {
+        trace_record(ck, OP_MUX, out, a, b, c);
+        return;
+    }
+    mux_now(ck, out, a, b, c);
 }
 
 int32_t orc_lwe_phase(const int32_t *sample, const int32_t *key, int32_t n)

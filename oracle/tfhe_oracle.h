@@ -86,8 +86,26 @@ void orc_gate_and(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const
 void orc_gate_xor(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb);
 void orc_gate_or(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb);
 void orc_gate_nand(const orc_cloudkey *ck, int32_t *out, const int32_t *ca, const int32_t *cb);
+/* bootsMUX(a,b,c) = a ? b : c (two bootstraps without key switch + one key switch) */
+void orc_gate_mux(const orc_cloudkey *ck, int32_t *out, const int32_t *a, const int32_t *b,
+                  const int32_t *c);
+/* tfhe_bootstrap_woKS_FFT: u is [k*N+1] under the extracted key */
+void orc_bootstrap_woks(const orc_cloudkey *ck, int32_t *u, const int32_t *x);
 /* number of bootstraps performed through this key since creation */
 uint64_t orc_cloudkey_bootstrap_count(const orc_cloudkey *ck);
+
+/* ---- deferred (level-parallel) evaluation of the SAME sequential gate stream ----
+ * Between orc_defer_begin() and orc_defer_run() every orc_gate_* call is only
+ * recorded; orc_defer_run() evaluates the recorded gates level by level on
+ * `nthreads` host threads (<= 0: all) and leaves every sample where the
+ * sequential run would have left it.  Bit-identical to the immediate mode. */
+void orc_defer_begin(orc_cloudkey *ck);
+int64_t orc_defer_run(orc_cloudkey *ck, int nthreads);
+void orc_scratch_free(const orc_cloudkey *ck, void *p);
+/* `count` independent two-input gates (type: 0 AND, 1 XOR, 2 OR, 3 NAND) on nthreads threads */
+void orc_gates_batch(const orc_cloudkey *ck, int32_t type, size_t count, int32_t *out,
+                     const int32_t *a, const int32_t *b, int nthreads);
+int orc_max_threads(void);
 
 /* exact negacyclic product mod (X^N+1, 2^32), for cross-checking back-ends */
 void orc_negacyclic_mul(int mode, int32_t N, int32_t *out, const int32_t *small, const int32_t *big);

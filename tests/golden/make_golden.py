@@ -79,6 +79,42 @@ def full_size_kat():
     print("full_gate_kat.npz written")
 
 
+def mul32_n630():
+    """BASELINE configs[2]'s circuit at the product parameter set: the oracle's own sequential
+    mul32 (oracle/cloud_oracle.c, cloud.c:115-218, 2655-2718) on ONE expression, 11 264 exact
+    bootstraps at n=630.  The gate stream is recorded and its independent gates evaluated on
+    all host cores (oracle/tfhe_oracle.c orc_defer_*; bit-identical to the sequential run, which
+    takes ~45 min).  Committed: operands, seeds, sha256 of the 64 output samples, and the first
+    and last sample in full; the key is regenerated from its seed (114 MB)."""
+    import time
+    p = ia.default_params()
+    seed = (314, 1592, 657)
+    k = tools.keygen_raw(p, seed)
+    ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, k["bk"], k["ksk"])
+    a, b, enc_seed = 0xDEADBEEF, 0x9ABCDEF1, 3001
+    S = p.n + 1
+    inb = np.zeros(96, dtype=np.uint8)
+    inb[:32] = tools.int_to_bits(a, 32)
+    inb[32:64] = tools.int_to_bits(b, 32)
+    inp = tools.encrypt_bits(p, k["lwe_key"], inb, enc_seed)  # A bits, B bits, carry word (zeros)
+    o1 = np.zeros((8, 32, S), np.int32)
+    o2 = np.zeros((8, 32, S), np.int32)
+    o1[0], o2[0] = inp[:32], inp[32:64]
+    t0 = time.time()
+    rc, out = ck.cloud_values(4, 0, 32, o1, o2, inp[64:96], threads=0)
+    assert rc == 0
+    res = np.ascontiguousarray(out[:2].reshape(64, S))  # low word, high word (cloud.c:2683-2686)
+    dec = tools.decrypt_bits(p, k["lwe_key"], res)
+    assert tools.bits_to_int(dec) == a * b
+    with open(os.path.join(HERE, "mul32_n630.json"), "w") as f:
+        json.dump({"params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2", "key_seed": list(seed),
+                   "a": a, "b": b, "encrypt_seed": enc_seed, "input_sha256": digest(inp),
+                   "output_sha256": digest(res), "first_sample": res[0].tolist(), "last_sample": res[-1].tolist(),
+                   "bootstraps": int(ck.bootstrap_count), "oracle_seconds": round(time.time() - t0, 1),
+                   "made_by": "tests/golden/make_golden.py mul32_n630 (oracle exact NTT back-end, deferred level-parallel mode)"}, f, indent=0)
+    print("mul32_n630.json written in %.0f s" % (time.time() - t0))
+
+
 def plaintext_kats():
     kats = []
     for bits in (32, 64, 128, 256):
@@ -99,6 +135,9 @@ def plaintext_kats():
 
 
 if __name__ == "__main__":
-    toy_vectors()
-    full_size_kat()
-    plaintext_kats()
+    if sys.argv[1:] == ["mul32_n630"]:  # ~6 min on 8 cores; not part of the default regeneration
+        mul32_n630()
+    else:
+        toy_vectors()
+        full_size_kat()
+        plaintext_kats()

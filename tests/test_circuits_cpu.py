@@ -21,6 +21,15 @@ APP_C = {  # (kind, bits): (bootstraps, and, xor, depth, max_width)
     (4, 64): (35296, 10336, 24960, 449, 4160),
     (4, 128): (121184, 37344, 83840, 1601, 16512),
     (5, 64): (35936, 10464, 25472, 451, 4161),
+    # fused chains: stage 1 + stage 2 of SURVEY App. C, e.g. BASELINE.md's A*B*C =
+    # 32-bit MUL (11 264) then 64-bit MUL (35 296) = 46 560; A+B*C at 32 bits = 11 264 + 64-bit ADD (320)
+    (5, 32): (11584, 3136, 8448, 257, 1057),
+    (5, 128): (122464, 37600, 84864, 1603, 16513),
+}
+CHAIN_COUNTS = {  # (k1, k2, bits): bootstraps = stage 1 + stage 2 at stage 2's width
+    (1, 1, 32): 160 + 160, (1, 2, 32): 160 + 320, (2, 2, 32): 320 + 320, (2, 1, 64): 640 + 320,
+    (4, 1, 32): 11264 + 320, (4, 2, 32): 11264 + 640, (4, 4, 32): 11264 + 35296, (4, 4, 64): 35296 + 121184,
+    (1, 4, 32): 160 + 11264,
 }
 
 
@@ -71,16 +80,86 @@ def test_mul_plaintext(ia, bits):
     assert _run(ia, 4, bits, 1 << (bits - 2), 1 << (bits - 2)) == 1 << (2 * bits - 4)
 
 
-def test_muladd_plaintext(ia):
-    rng = np.random.default_rng(5)
-    for _ in range(3):
-        a, b = (int.from_bytes(rng.bytes(8), "little") for _ in range(2))
-        c = int.from_bytes(rng.bytes(16), "little")
-        assert _run(ia, 5, 64, a, b, c) == (a * b + c) % (1 << 128)
+@pytest.mark.parametrize("bits", [32, 64, 128])
+def test_muladd_plaintext(ia, bits):
+    rng = np.random.default_rng(5 + bits)
+    for _ in range({32: 3, 64: 3, 128: 1}[bits]):
+        a, b = (int.from_bytes(rng.bytes(bits // 8), "little") for _ in range(2))
+        c = int.from_bytes(rng.bytes(bits // 4), "little")
+        assert _run(ia, 5, bits, a, b, c) == (a * b + c) % (1 << (2 * bits))
+    assert ia.circ_chain(ia.CIRC_MUL, ia.CIRC_ADD) != 5  # MULADD keeps its own code, same DAG
+    i5, ic = ia.circuit_info(5, bits), ia.circuit_info(ia.circ_chain(ia.CIRC_MUL, ia.CIRC_ADD), bits)
+    assert (i5.bootstraps, i5.depth, i5.n_inputs) == (ic.bootstraps, ic.depth, ic.n_inputs)
+
+
+def _run_chain(ia, k1, k2, flip, bits, a, b, c, fold=False):
+    """plaintext run of IEACHE_CIRC_CHAIN(k1, k2, flip): inputs A, B, carry word, C [, C's carry word]"""
+    from ieache_amd.tools import int_to_bits, bits_to_int
+    kind = ia.circ_chain(k1, k2, flip)
+    info = ia.circuit_info(kind, bits, fold)
+    w2 = 2 * bits if k1 == 4 else bits
+    assert info.n_inputs == 2 * bits + 32 + w2 + (0 if flip else 32)
+    assert info.n_outputs == (2 * w2 if k2 == 4 else w2)
+    x = np.zeros(info.n_inputs, dtype=np.uint8)
+    x[:bits] = int_to_bits(a, bits)
+    x[bits:2 * bits] = int_to_bits(b, bits)
+    x[2 * bits + 32:2 * bits + 32 + w2] = int_to_bits(c, w2)
+    return bits_to_int(ia.circuit_simulate(kind, bits, x, fold)), info
+
+
+def _stage(k, x, y, m):
+    return {1: (x + y) % m, 2: (x - y) % m, 3: (y - x) % m, 4: x * y}[k]
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_chained_operators_plaintext(ia, fold):
+    """compute() + compute_final() (dragonfly_cipher_cloud.py:1219-1327) fused: every operator pair the paper
+    times (AC058.pdf Fig. 7: A+B+C, A+B-C, A+B*C, A-B*C, A-B-C, A*B*C) and both operand orders."""
+    rng = np.random.default_rng(77)
+    for bits in (32, 64):
+        m = 1 << bits
+        a, b = (int.from_bytes(rng.bytes(bits // 8), "little") for _ in range(2))
+        for k1 in (1, 2, 3, 4):
+            w2 = 2 * bits if k1 == 4 else bits
+            c = int.from_bytes(rng.bytes(w2 // 8), "little")
+            for k2 in (1, 2, 3, 4):
+                if k2 == 4 and (w2 > 128 or (bits == 64 and k1 != 4)):
+                    continue  # keep the CPU suite short: one 128-bit stage-2 multiplier is enough
+                for flip in (True, False):
+                    s1 = _stage(k1, a, b, m)
+                    exp = _stage(k2, s1, c, 1 << w2) if flip else _stage(k2, c, s1, 1 << w2)
+                    got, info = _run_chain(ia, k1, k2, flip, bits, a, b, c, fold)
+                    assert got == exp, (bits, k1, k2, flip)
+                    if not fold and (k1, k2, bits) in CHAIN_COUNTS:
+                        assert info.bootstraps == info.reference_bootstraps == CHAIN_COUNTS[(k1, k2, bits)]
+
+
+def test_constant_folded_circuits(ia):
+    """Opt-in folding (SURVEY App. C note): same plaintext function, fewer bootstraps, reference count kept."""
+    from ieache_amd.tools import int_to_bits, bits_to_int
+    rng = np.random.default_rng(31)
+    for kind, bits, min_gain in ((1, 32, 1.0), (2, 32, 1.2), (3, 64, 1.2), (4, 32, 1.4), (4, 64, 1.2), (5, 32, 1.4), (6, 32, 1.0)):
+        plain, folded = ia.circuit_info(kind, bits), ia.circuit_info(kind, bits, fold=True)
+        assert plain.folded == 0 and folded.folded == 1
+        assert plain.reference_bootstraps == plain.bootstraps == folded.reference_bootstraps
+        assert folded.bootstraps * min_gain <= plain.bootstraps and folded.depth <= plain.depth
+        assert folded.n_and + folded.n_xor == folded.bootstraps
+        for _ in range(4):
+            x = rng.integers(0, 2, size=plain.n_inputs, dtype=np.uint8)
+            x[2 * bits:2 * bits + 32] = 0
+            assert np.array_equal(ia.circuit_simulate(kind, bits, x), ia.circuit_simulate(kind, bits, x, fold=True))
+    # the carry word's bit 0 is still a live carry-in after folding
+    x = np.zeros(96, dtype=np.uint8)
+    x[:32], x[32:64], x[64] = int_to_bits(5, 32), int_to_bits(6, 32), 1
+    assert bits_to_int(ia.circuit_simulate(1, 32, x, fold=True)) == 12
+    assert ia.circuit_info(4, 32, fold=True).bootstraps == 7568  # regression pin: 11 264 in the reference
 
 
 def test_unsupported_circuits_rejected(ia):
-    for kind, bits in [(4, 256), (4, 16), (5, 32), (9, 32), (1, 0), (1, 257)]:
+    bad = [(4, 256), (4, 16), (5, 16), (5, 256), (9, 32), (1, 0), (1, 257), (64, 32),
+           (ia.circ_chain(4, 4), 128),   # stage 2 would be a 256-bit MUL: cloud.c:860-864 exits 126
+           (ia.circ_chain(1, 4), 256), (ia.circ_chain(4, 1), 48)]
+    for kind, bits in bad:
         with pytest.raises(ia.IeacheError):
             ia.circuit_info(kind, bits)
 

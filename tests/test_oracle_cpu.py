@@ -142,6 +142,49 @@ def test_cloud_values_64bit(O, toy):
     assert ck.cloud_values(1, 0, 48, o1, o2, carry)[0] == -1  # no branch of main() matches
 
 
+def test_deferred_level_parallel_mode_is_bit_identical(O, toy):
+    """orc_defer_*: the oracle's own sequential gate stream, recorded and evaluated level by level on
+    several threads, leaves exactly the bits of the immediate run (it is how the n=630 goldens are made)."""
+    K, ck = toy
+    carry = K.encrypt_word(0)
+    o1, o2 = _operand(K, 0xFEDCBA9876543210), _operand(K, 0x0F1E2D3C4B5A6978)
+    for op, neg, bits in ((1, 0, 64), (2, 0, 32), (1, 1, 64), (1, 2, 32), (4, 0, 32)):
+        before = ck.bootstrap_count
+        rc1, seq = ck.cloud_values(op, neg, bits, o1, o2, carry)
+        n_seq = ck.bootstrap_count - before
+        before = ck.bootstrap_count
+        rc2, par = ck.cloud_values(op, neg, bits, o1, o2, carry, threads=3)
+        assert rc1 == rc2 == 0 and np.array_equal(seq, par), (op, neg, bits)
+        assert ck.bootstrap_count - before == n_seq
+    # independent gates in one batch
+    a = np.stack([K.encrypt_bits(v) for v in (0, 0, 1, 1, 1)])
+    b = np.stack([K.encrypt_bits(v) for v in (0, 1, 0, 1, 1)])
+    for name in ("and", "xor", "or", "nand"):
+        assert np.array_equal(ck.gates_batch(name, a, b, threads=2), np.stack([ck.gate(name, a[i], b[i]) for i in range(5)]))
+    assert O.max_threads() >= 1
+
+
+def test_mux_gate(O, toy):
+    """bootsMUX(a,b,c) = a ? b : c: two bootstraps without key switch, one key switch (boot-gates.cpp)."""
+    K, ck = toy
+    for a in (0, 1):
+        for b in (0, 1):
+            for c in (0, 1):
+                ca, cb, cc = K.encrypt_bits(a), K.encrypt_bits(b), K.encrypt_bits(c)
+                out = ck.mux(ca, cb, cc)
+                ph = int(K.phase(out))
+                assert (ph > 0) == bool(b if a else c), (a, b, c)
+                assert abs(abs(ph) - MU) < MU // 2
+                # = keyswitch((0,1/8) + woKS(AND(a,b)) + woKS(AND(NOT a, c)))
+                t1 = (ca.astype(np.int64) + cb).astype(np.int32)
+                t1[-1] = np.int32((int(t1[-1]) - MU + 2 ** 31) % 2 ** 32 - 2 ** 31)
+                t2 = (cc.astype(np.int64) - ca).astype(np.int32)
+                t2[-1] = np.int32((int(t2[-1]) - MU + 2 ** 31) % 2 ** 32 - 2 ** 31)
+                u = (ck.bootstrap_woks(t1).astype(np.int64) + ck.bootstrap_woks(t2)).astype(np.int32)
+                u[-1] = np.int32((int(u[-1]) + MU + 2 ** 31) % 2 ** 32 - 2 ** 31)
+                assert np.array_equal(ck.keyswitch(u), out)
+
+
 def test_metadata_dispatch_table(O):
     """SURVEY section 8a truth table (cloud.c:787-864)."""
     # (op, neg1, neg2) -> (code written, routing neg)

@@ -100,7 +100,10 @@ def test_key_files_roundtrip_and_sizes(ia, tmp_path):
     assert not np.array_equal(nlwe, lwe)  # different seed (keygen.c:34)
     raw = (tmp_path / "cloud.key").read_bytes()
     assert raw.startswith(b"-----BEGIN GATEBOOTSPARAMS-----\n")
-    hdr_end = raw.index(b"-----END TLWEPARAMS-----\n") + len(b"-----END TLWEPARAMS-----\n")
+    # libtfhe's section order as best known: write_tGswParams emits its TLWEPARAMS first
+    order = [raw.index(b"-----BEGIN %s-----" % t) for t in (b"GATEBOOTSPARAMS", b"LWEPARAMS", b"TLWEPARAMS", b"TGSWPARAMS")]
+    assert order == sorted(order)
+    hdr_end = raw.index(b"-----END TGSWPARAMS-----\n") + len(b"-----END TGSWPARAMS-----\n")
     # body: tag, KS tag, variance, KS coefficients (all `base` entries), variance, BK coefficients
     assert len(raw) - hdr_end == 4 + 4 + 8 + p.ksk_count * 4 + 8 + p.bk_count * 4
     sec = (tmp_path / "secret.key").stat().st_size
@@ -114,6 +117,97 @@ def test_key_files_roundtrip_and_sizes(ia, tmp_path):
         tools.read_cloud_key(tmp_path / "bad2.key")
     with pytest.raises(ia.IeacheError):
         tools.read_cloud_key(tmp_path / "missing.key")
+
+
+def _sections(raw):
+    """split a key file written by this build into its four text sections and the binary rest"""
+    secs = {}
+    for t in (b"GATEBOOTSPARAMS", b"LWEPARAMS", b"TLWEPARAMS", b"TGSWPARAMS"):
+        a = raw.index(b"-----BEGIN %s-----\n" % t)
+        e = b"-----END %s-----\n" % t
+        b = raw.index(e) + len(e)
+        secs[t] = raw[a:b]
+    body = raw[raw.index(b"-----END TGSWPARAMS-----\n") + len(b"-----END TGSWPARAMS-----\n"):]
+    return secs, body
+
+
+def test_key_reader_tolerates_other_layouts(ia, tmp_path):
+    """SURVEY App. B codec strategy: no libtfhe-written file exists here, so the reader finds text
+    sections by title in any order and solves for the binary layout among enumerated hypotheses.
+    Every variant below carries the same key and must load to the same arrays."""
+    import struct
+    from ieache_amd import tools
+    L = ia.lib()
+    p = ia.default_params().copy(n=7, N=32)
+    tools.keygen_files(tmp_path, p, seed=(5, 6, 7), nbit_seed=(8, 9))
+    ref = tools.keygen_raw(p, (5, 6, 7))
+    bk, ksk = ref["bk"].ravel(), ref["ksk"].ravel()
+    raw = (tmp_path / "cloud.key").read_bytes()
+    secs, body = _sections(raw)
+    tools.read_cloud_key(tmp_path / "cloud.key")
+    assert b"KS{tag, one variance, all base rows} then BK{one variance}" in L.ieache_last_key_layout()
+    G, LW, TL, TG = (secs[t] for t in (b"GATEBOOTSPARAMS", b"LWEPARAMS", b"TLWEPARAMS", b"TGSWPARAMS"))
+    i32 = lambda v: struct.pack("<i", v)
+    f64 = lambda v: struct.pack("<d", v)
+    S = p.n + 1
+    ksk4 = ksk.reshape(-1, 4, S)  # [N*t][base][n+1]
+    ks_lwe = b"-----BEGIN LWEKSPARAMS-----\nbasebit: 2\nn: 32\nt: 8\n-----END LWEKSPARAMS-----\n"
+    variants = {
+        # this build's earlier header order (TGSW before TLWE) and a shuffled one
+        "old_order": (G + LW + TG + TL + body, b"KS{tag, one variance"),
+        "shuffled": (TL + G + TG + LW + body, b"KS{tag, one variance"),
+        # property lines reordered inside a section, CRLF-free variants keep working
+        "props": (G + b"-----BEGIN LWEPARAMS-----\nn: 7\nalpha_min: %.17g\nalpha_max: %.17g\n-----END LWEPARAMS-----\n"
+                  % (p.lwe_alpha_min, p.lwe_alpha_max) + TL + TG + body, b"KS{tag"),
+        # no type tags, no variances
+        "bare": (G + LW + TL + TG + ksk.tobytes() + bk.tobytes(), b"KS{no variance, all base rows} then BK{no variance}"),
+        # bootstrapping key first, key-switch key with its own text section in between (write_lweKeySwitchKey)
+        "bk_first": (G + LW + TL + TG + i32(201) + f64(-1.0) + bk.tobytes() + ks_lwe + i32(200) + f64(2.0 ** -30) + ksk.tobytes(),
+                     b"BK{one variance} then KS{tag, one variance, all base rows}"),
+        # the never-read d = 0 rows left out
+        "no_d0": (G + LW + TL + TG + i32(201) + i32(200) + f64(0.0) + np.ascontiguousarray(ksk4[:, 1:]).tobytes() + f64(0.0) + bk.tobytes(),
+                  b"d=0 rows omitted"),
+        # a variance double after every key-switch sample and every TLWE row
+        "per_sample": (G + LW + TL + TG + i32(201) + i32(200)
+                       + b"".join(r.tobytes() + f64(1e-9) for r in ksk.reshape(-1, S))
+                       + b"".join(r.tobytes() + f64(1e-15) for r in bk.reshape(-1, 2 * p.N)),
+                       b"KS{tag, variance per sample, all base rows} then BK{variance per sample}"),
+    }
+    for name, (blob, want) in variants.items():
+        f = tmp_path / (name + ".key")
+        f.write_bytes(blob)
+        q, b2, k2 = tools.read_cloud_key(f)
+        assert bytes(q) == bytes(p), name
+        assert np.array_equal(b2, bk), name
+        got = k2.reshape(-1, 4, S)
+        assert np.array_equal(got[:, 1:], ksk4[:, 1:]) and not got[:, 0].any(), name
+        assert want in L.ieache_last_key_layout(), (name, L.ieache_last_key_layout())
+    # secret key sets: keys before the cloud body, untagged, TGSW key first
+    sraw = (tmp_path / "secret.key").read_bytes()
+    _, sbody = _sections(sraw)
+    cloud_body = sbody[:len(body)]
+    lwe, tlwe = ref["lwe_key"], ref["tlwe_key"]
+    hdr = G + LW + TL + TG
+    svariants = {
+        "keys_first": hdr + i32(43) + lwe.tobytes() + i32(202) + tlwe.tobytes() + cloud_body,
+        "untagged": hdr + cloud_body + lwe.tobytes() + tlwe.tobytes(),
+        "tgsw_first": hdr + cloud_body + i32(202) + tlwe.tobytes() + i32(43) + lwe.tobytes(),
+    }
+    for name, blob in svariants.items():
+        f = tmp_path / (name + ".skey")
+        f.write_bytes(blob)
+        q, l2, t2 = tools.read_secret_key(f)
+        assert np.array_equal(l2, lwe) and np.array_equal(t2, tlwe), name
+    # nothing fits: the message says how many bytes were left and for which parameters
+    (tmp_path / "odd.key").write_bytes(raw + b"\0\0\0")
+    with pytest.raises(ia.IeacheError, match="no key layout fits"):
+        tools.read_cloud_key(tmp_path / "odd.key")
+    (tmp_path / "tag.key").write_bytes(hdr + i32(201) + i32(999) + body[8:])
+    with pytest.raises(ia.IeacheError, match="no key layout fits"):
+        tools.read_cloud_key(tmp_path / "tag.key")
+    (tmp_path / "ks.key").write_bytes(hdr + ks_lwe.replace(b"t: 8", b"t: 5") + body)
+    with pytest.raises(ia.IeacheError, match="LWEKSPARAMS"):
+        tools.read_cloud_key(tmp_path / "ks.key")
 
 
 def test_sample_stream_layout(ia, tmp_path):
