@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_pmc_summary.txt (made by scripts/pmc_passes.sh over `scripts/br_bench.py 8192`) ->
+profiles/traffic.json, the committed counter evidence bench.py's roofline reads.
+
+HBM bytes as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) is doubled
+(wide coalesced reads are tallied at 64 B per 128-B request), WRITE_SIZE (KB) taken as is, separate passes.
+
+  python scripts/pmc_to_traffic.py profiles/r2_a_pmc_summary.txt [gates_per_launch=8192] [cmux_steps_per_launch=16]
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+summary = sys.argv[1]
+gates = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+vals = {}
+for line in open(summary):
+    m = re.match(r"(BR|KS) (\S+)\s+n=(\d+) avg=([0-9.e+-]+)", line)
+    if m:
+        vals[(m.group(1), m.group(2))] = float(m.group(4))
+rel = os.path.relpath(os.path.abspath(summary), ROOT)
+
+
+def hbm(k):
+    return (2.0 * vals[(k, "FETCH_SIZE")] + vals[(k, "WRITE_SIZE")]) * 1024.0
+
+
+out = {
+    "w2x64-radix8-registers": {
+        "kernel": "k_blind_rotate_w2<3,7>", "pmc_summary": rel,
+        "source": rel + " (scripts/pmc_passes.sh: separate rocprofv3 --pmc passes over scripts/br_bench.py %d)" % gates,
+        "gates_per_launch": gates, "cmux_steps_per_launch": steps,
+        "FETCH_SIZE_KB_avg": vals[("BR", "FETCH_SIZE")], "WRITE_SIZE_KB_avg": vals[("BR", "WRITE_SIZE")],
+        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is; x1024 B",
+        "hbm_bytes_per_launch": hbm("BR"), "hbm_bytes_per_gate_step": hbm("BR") / (gates * steps),
+        "l2_hit_rate": vals[("BR", "TCC_HIT_sum")] / (vals[("BR", "TCC_HIT_sum")] + vals[("BR", "TCC_MISS_sum")]),
+        "SQ_INSTS_VALU_per_launch": vals[("BR", "SQ_INSTS_VALU")],
+        "valu_insts_per_gate_step": vals[("BR", "SQ_INSTS_VALU")] / (gates * steps),
+        "SQ_INSTS_LDS_per_gate_step": vals[("BR", "SQ_INSTS_LDS")] / (gates * steps),
+        "valu_busy_of_wave_cycles_x_waves_per_simd": 2 * vals[("BR", "SQ_ACTIVE_INST_VALU")] / vals[("BR", "SQ_WAVE_CYCLES")],
+        "effective_clock_GHz_note": "GRBM_GUI_ACTIVE / 8 XCDs = %.3e shader cycles per launch" % (vals[("BR", "GRBM_GUI_ACTIVE")] / 8),
+    },
+    "keyswitch_sliced": {
+        "kernel": "k_keyswitch_sliced<G>", "pmc_summary": rel, "gates_per_launch": gates,
+        "FETCH_SIZE_KB_avg": vals[("KS", "FETCH_SIZE")], "WRITE_SIZE_KB_avg": vals[("KS", "WRITE_SIZE")],
+        "hbm_bytes_per_launch": hbm("KS"),
+        "l2_hit_rate": vals[("KS", "TCC_HIT_sum")] / (vals[("KS", "TCC_HIT_sum")] + vals[("KS", "TCC_MISS_sum")]),
+    },
+}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out["w2x64-radix8-registers"], indent=1))
