@@ -915,7 +915,10 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
            hipStream_t stream) {
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
-    const size_t lds = lds_bytes(p);
+    // IEACHE_BR_LDS_PAD=<bytes>: measurement aid -- extra dynamic LDS per workgroup lowers the number of
+    // resident workgroups per CU (35.8 KB -> 4; +6 KB -> 3; +18 KB -> 2), i.e. waves per SIMD, at unchanged code
+    static const size_t lds_pad = getenv("IEACHE_BR_LDS_PAD") ? (size_t)atol(getenv("IEACHE_BR_LDS_PAD")) : 0;
+    const size_t lds = lds_bytes(p) + lds_pad;
     const int32_t nb = bara_stride(p);
     // state block: [items][2][1024] int32 accumulators, then [items][nb] u16 rotation amounts
     int32_t* st_acc = reinterpret_cast<int32_t*>(state);

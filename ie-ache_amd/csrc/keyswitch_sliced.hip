@@ -22,6 +22,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <stdexcept>
+
 namespace ieache {
 namespace kss {
 
@@ -201,12 +203,18 @@ __global__ __launch_bounds__(256) void k_keyswitch_sliced(DevKeys K, WorkDesc W,
                      : "+{v[32:63]}"(acc[0]), "=&{v[64:95]}"(t0), "=&{v[96:127]}"(t1), "=&{v[128:131]}"(t2), KS_IO);
     } else {
         static_assert(G == 4, "G is 4, 8, 16 or 32");
-        // accumulators in the low half of acc[0] (v[32:47]); its high half holds the row table
+        // four gates = 16 accumulator registers (v[32:47]); the row table gets its own operand (v[48:63])
+        // instead of living in the unused half of a 32-register accumulator vector
+        v16i a4, tb;
         v32i t0;
         v16i t1;
         v2i t2;
+#pragma unroll
+        for (int e = 0; e < 16; e++) a4[e] = acc[0][e];
         asm volatile(KS_WALK(48, 64, 76, 88, 100, KS_GATES_G4, KS_DIGITS_G4(112), 8)
-                     : "+{v[32:63]}"(acc[0]), "=&{v[64:95]}"(t0), "=&{v[96:111]}"(t1), "=&{v[112:113]}"(t2), KS_IO);
+                     : "+{v[32:47]}"(a4), "=&{v[48:63]}"(tb), "=&{v[64:95]}"(t0), "=&{v[96:111]}"(t1), "=&{v[112:113]}"(t2), KS_IO);
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[0][e] = a4[e];
     }
 #undef KS_IO
     if (active) {
@@ -235,7 +243,7 @@ static void launch_g(const DevKeys& K, const WorkDesc& W, int64_t items, const T
         return hipFuncSetAttribute((const void*)k_keyswitch_sliced<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) ==
                hipSuccess;
     }();
-    (void)attr;
+    if (!attr) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_keyswitch_sliced");
     hipLaunchKernelGGL(k_keyswitch_sliced<G>, dim3((unsigned)((items + G - 1) / G)), dim3(64 * nld), (size_t)(i1 - i0) * G * 2, stream,
                        K, W, ext, flat_out, items, i0, i1);
 }
