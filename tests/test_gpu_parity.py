@@ -506,6 +506,17 @@ def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
             rc2, ref = ck.cloud_values(kat["op"], neg, kat["bits"], data[2:10], data[13:21], data[10])
             ans = tools.read_samples(tmp_path / "answer.data", p.n).reshape(11, 32, p.n + 1)
             assert rc2 == 0 and np.array_equal(ans[2:], ref), kat
+        # cloud.c reads exactly 22 arrays of 32 samples (:703-766; the 22nd, ciphertextcarry2, is read and never
+        # used); anything a caller left behind them is not looked at, a shorter file is an I/O error
+        _run_file_contract(ia, tmp_path, 1, 1, 32, 77, 0, 23, 0, ctx=ctx)
+        good = (tmp_path / "cloud.data").read_bytes()
+        assert len(good) == 704 * S and tools.verif_interpret(1, *tools.verif(tmp_path)) == 100
+        (tmp_path / "cloud.data").write_bytes(good + good[:32 * S])  # a 23rd word
+        rc, size, ok = ia.compute(1, tmp_path, ctx=ctx, failure_size=64 * S)
+        assert (rc, ok) == (0, True) and tools.verif_interpret(1, *tools.verif(tmp_path)) == 100
+        (tmp_path / "cloud.data").write_bytes(good[:-S])              # last sample of the 22nd word missing
+        with pytest.raises(ia.IeacheError):
+            ctx.cloud_run(tmp_path)
     # the `cloud` executable shim honours the same contract (exit code, files in cwd)
     rc, size, ok = _run_file_contract(ia, tmp_path, 1, 1, 32, 1 << 30, 0, 1 << 30, 0, use_subprocess=True)
     assert (rc, ok) == (0, True)
