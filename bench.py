@@ -60,7 +60,7 @@ def pmc_counters(kernel_variant):
         if not tj:
             return None
         out = {"hbm_bytes_per_gate_step": tj["hbm_bytes_per_gate_step"], "l2_hit_rate": tj.get("l2_hit_rate"),
-               "source": tj.get("pmc_summary", tj.get("source"))}
+               "source": tj.get("pmc_summary", tj.get("source")), "shader_cycles_per_gate_step": tj.get("shader_cycles_per_gate_step")}
         summ = tj.get("pmc_summary")
         if summ:
             for line in open(os.path.join(ROOT, summ)):
@@ -99,6 +99,13 @@ def roofline(p, stats, gate_rate, pmc):
                     "valu_insts_per_gate": insts * p.n, "valu_insts_source": pmc.get("source"),
                     "note": "achieved = blind-rotation gates/s (HIP events over its launches) x SQ_INSTS_VALU per gate x 64 lanes x 2 flop; "
                             "100 %% = %.0f gates/s per GPU at 2.4 GHz" % (FP64_VALU_PEAK_TFLOPS * 1e12 / flop_per_gate)})
+        cyc = pmc.get("shader_cycles_per_gate_step")
+        if cyc and br_avg_ms > 0:
+            # the chip lowers its clock under this load (DVFS give-back): shader cycles of a launch from GRBM_GUI_ACTIVE / 8
+            # (PMC run, scaled to this leg's launch geometry) over the launch time measured here
+            ghz = cyc * gates_per_launch * steps_per_launch / (br_avg_ms * 1e-3) / 1e9
+            out["effective_clock_GHz"] = ghz
+            out["frac_at_effective_clock"] = out["frac"] * 2.4 / ghz
     else:
         out.update({"bound": "fp64_valu", "unit": "TFLOP/s", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "frac": None,
                     "note": "no committed SQ_INSTS_VALU for this kernel variant"})

@@ -220,7 +220,10 @@ constexpr int kTile = 8 * 72;  // double2 elements per tile (9216 B)
 // Forward 512-point transform of the twisted polynomial.
 //   in : x[r] = y_{64r+lane} * exp(i*pi*r/16)  (the lane part tL of the twist is applied here)
 //   out: x[k2] = X[k0 + 8*k1 + 64*k2] with lane = 8*k0 + k1
-template <bool WSYNC, int XLANE = 0>
+// ILV: issue each ds_write right behind the multiply that produces its data instead of as a burst of 8 after
+// all of them (left alone the compiler clusters the stores): the wave's own LDS-store issue (~13 cycles each on
+// CDNA4) then runs under its next twiddle multiply instead of stalling its instruction stream.
+template <bool WSYNC, int XLANE = 0, int ILV = 0>
 __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
@@ -230,6 +233,37 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
 #pragma unroll
     for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
     dft8<false>(x);                          // over r -> k0
+    if (ILV && !(XLANE & 1)) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            x[k] = cmulx<false>(x[k], tA[k]);
+            sT[own + 72 * k] = x[k];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
+        tile_sync<WSYNC>();
+#pragma unroll
+        for (int p1 = 0; p1 < 8; p1++) x[p1] = sT[blk + 9 * p1];
+        tile_sync<WSYNC>();
+        dft8<false>(x);
+        sT[blk] = x[0];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+            x[k] = cmulx<false>(x[k], tB[k]);
+            sT[blk + 9 * k] = x[k];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile_sync<WSYNC>();
+        const int rd2 = hi * 72 + lo * 9;
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = sT[rd2 + q];
+        tile_sync<WSYNC>();
+        dft8<false>(x);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = cmulx<false>(x[k], tA[k]);  // * tL * w512^(lane*k0)
 #pragma unroll
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(128) void k_br_prologue(DevKeys K, WorkDesc W, uint
 // limbs) and inverse-transforms them.  Each forward spectrum is handed to the
 // partner wave through the producing wave's own (then idle) transpose tile.
 // dynamic LDS: sT [2][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32
-template <int L, int BGBIT, bool DIAG, bool WSYNC, int XLANE = 0>
+template <int L, int BGBIT, bool DIAG, bool WSYNC, int XLANE = 0, int ILV = 0>
 __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf,
                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
                                                            int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
@@ -532,7 +566,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 #pragma unroll
             for (int k = 0; k < 8; k++) bA[k] = bown[k * 64];
             __builtin_amdgcn_sched_barrier(0);
-            fft512_forward<WSYNC, XLANE>(x, sT, lane, R);
+            fft512_forward<WSYNC, XLANE, ILV>(x, sT, lane, R);
             IEACHE_STAMP(1)
             // hand the spectrum to the partner wave through our own (now idle) tile
 #pragma unroll
@@ -895,6 +929,7 @@ static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream
         case 3: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
         case 4: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw); break;
         case 5: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
+        case 10: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 0, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
         case 6: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 2>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
         default: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
     }
@@ -926,7 +961,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
     hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
-    const int32_t max_slice = variant >= kVariantWide ? nb : 64;
+    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;

@@ -41,7 +41,8 @@ out = {
         "valu_insts_per_gate_step": vals[("BR", "SQ_INSTS_VALU")] / (gates * steps),
         "SQ_INSTS_LDS_per_gate_step": vals[("BR", "SQ_INSTS_LDS")] / (gates * steps),
         "valu_busy_of_wave_cycles_x_waves_per_simd": 2 * vals[("BR", "SQ_ACTIVE_INST_VALU")] / vals[("BR", "SQ_WAVE_CYCLES")],
-        "effective_clock_GHz_note": "GRBM_GUI_ACTIVE / 8 XCDs = %.3e shader cycles per launch" % (vals[("BR", "GRBM_GUI_ACTIVE")] / 8),
+        "shader_cycles_per_gate_step": vals[("BR", "GRBM_GUI_ACTIVE")] / 8 / (gates * steps),
+        "effective_clock_GHz_note": "GRBM_GUI_ACTIVE / 8 XCDs = %.3e shader cycles per launch (MI355X_MICROARCH.md, DVFS give-back: effective clock = that / kernel wall time)" % (vals[("BR", "GRBM_GUI_ACTIVE")] / 8),
     },
     "keyswitch_sliced": {
         "kernel": "k_keyswitch_sliced<G>", "pmc_summary": rel, "gates_per_launch": gates,

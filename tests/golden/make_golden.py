@@ -115,6 +115,43 @@ def mul32_n630():
     print("mul32_n630.json written in %.0f s" % (time.time() - t0))
 
 
+def muladd64_n630():
+    """BASELINE configs[3]'s circuit at the product parameter set: 64-bit a*b+c as the reference evaluates it
+    -- compute() = MUL at 64 bits, then compute_final() = ADD at 128 bits on [answer | c]
+    (dragonfly_cipher_cloud.py:1219-1327) -- by the oracle's two sequential cloud.c runs: 35 296 + 640 exact
+    bootstraps at n=630 (deferred level-parallel mode; ~40 min on 8 cores).  Committed: operands, seeds,
+    sha256 of the 128 output samples, first and last sample."""
+    import time
+    p = ia.default_params()
+    seed = (314, 1592, 657)
+    k = tools.keygen_raw(p, seed)
+    ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, k["bk"], k["ksk"])
+    a, b, c, enc_seed = 0xFEDCBA9876543210, 0x0F1E2D3C4B5A6978, (1 << 127) | 0x1234567890ABCDEF, 3002
+    S = p.n + 1
+    inb = np.zeros(2 * 64 + 32 + 128, dtype=np.uint8)  # IEACHE_CIRC_MULADD inputs: A, B, carry word, C (128 bits)
+    inb[:64], inb[64:128], inb[160:] = tools.int_to_bits(a, 64), tools.int_to_bits(b, 64), tools.int_to_bits(c, 128)
+    inp = tools.encrypt_bits(p, k["lwe_key"], inb, enc_seed)
+    o1 = np.zeros((8, 32, S), np.int32)
+    o2 = np.zeros((8, 32, S), np.int32)
+    o1[:2], o2[:2] = inp[:64].reshape(2, 32, S), inp[64:128].reshape(2, 32, S)
+    t0 = time.time()
+    rc, st1 = ck.cloud_values(4, 0, 64, o1, o2, inp[128:160], threads=0)
+    assert rc == 0
+    C = np.zeros((8, 32, S), np.int32)
+    C[:4] = inp[160:].reshape(4, 32, S)
+    rc, st2 = ck.cloud_values(1, 0, 128, np.ascontiguousarray(st1[:8]), C, inp[128:160], threads=0)
+    assert rc == 0
+    res = np.ascontiguousarray(st2[:4].reshape(128, S))
+    assert tools.bits_to_int(tools.decrypt_bits(p, k["lwe_key"], res)) == (a * b + c) % (1 << 128)
+    with open(os.path.join(HERE, "muladd64_n630.json"), "w") as f:
+        json.dump({"params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2", "key_seed": list(seed),
+                   "a": a, "b": b, "c": c, "encrypt_seed": enc_seed, "input_sha256": digest(inp),
+                   "output_sha256": digest(res), "first_sample": res[0].tolist(), "last_sample": res[-1].tolist(),
+                   "bootstraps": int(ck.bootstrap_count), "oracle_seconds": round(time.time() - t0, 1),
+                   "made_by": "tests/golden/make_golden.py muladd64_n630 (oracle exact NTT back-end, two cloud.c runs, deferred level-parallel mode)"}, f, indent=0)
+    print("muladd64_n630.json written in %.0f s" % (time.time() - t0))
+
+
 def plaintext_kats():
     kats = []
     for bits in (32, 64, 128, 256):
@@ -135,8 +172,10 @@ def plaintext_kats():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["mul32_n630"]:  # ~6 min on 8 cores; not part of the default regeneration
+    if sys.argv[1:] == ["mul32_n630"]:  # ~12 min on 8 cores; not part of the default regeneration
         mul32_n630()
+    elif sys.argv[1:] == ["muladd64_n630"]:  # ~40 min on 8 cores
+        muladd64_n630()
     else:
         toy_vectors()
         full_size_kat()
