@@ -367,6 +367,26 @@ def test_mul32_at_product_parameters_matches_golden(ia, gpu_ctx):
     assert all(np.array_equal(outs[e], out) for e in range(24))
 
 
+def test_muladd64_at_product_parameters_matches_golden(ia, gpu_ctx):
+    """BASELINE configs[3]'s circuit at n=630: the fused 64-bit a*b+c (35 936 bootstraps, 451 levels) equals, sample for
+    sample, what the oracle's two sequential cloud.c runs produced offline (tests/golden/muladd64_n630.json)."""
+    import hashlib
+    from ieache_amd.tools import bits_to_int, int_to_bits
+    path = os.path.join(G, "muladd64_n630.json")
+    g = json.load(open(path))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(g["key_seed"]))
+    inb = np.zeros(2 * 64 + 32 + 128, dtype=np.uint8)
+    inb[:64], inb[64:128], inb[160:] = int_to_bits(g["a"], 64), int_to_bits(g["b"], 64), int_to_bits(g["c"], 128)
+    inp = kb.enc(inb, g["encrypt_seed"])
+    assert hashlib.sha256(np.ascontiguousarray(inp).tobytes()).hexdigest() == g["input_sha256"]
+    st = ia.Stats()
+    out = ctx.eval_batch(ia.CIRC_MULADD, 64, inp[None], st)[0]
+    assert st.bootstraps == 35936 == g["bootstraps"] and st.levels == 451
+    assert bits_to_int(kb.dec(out)) == (g["a"] * g["b"] + g["c"]) % (1 << 128)
+    assert out[0].tolist() == g["first_sample"] and out[-1].tolist() == g["last_sample"]
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == g["output_sha256"]
+
+
 def test_noise_margin_of_bootstrapped_outputs(ia, gpu_ctx):
     """SURVEY section 7 step 1 at the product parameter set: the phase error of bootstrapped outputs against
     the analytic variance of TFHE gate bootstrapping (Keygen/keygen.c:22-23's set: sigma_bk = 2^-25, sigma_ks =
@@ -550,8 +570,8 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         ctx.set_option("br_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref), sl
     ctx.set_option("br_slice", 16)
-    for variant in (2, 3):                                 # workgroup-barrier sync; cross-lane (DPP/permlane) transposes
-        ctx.set_option("br_variant", variant)
+    for variant in (2, 3, 5, 6, 10):                       # workgroup-barrier sync; cross-lane (DPP/permlane) transposes: both /
+        ctx.set_option("br_variant", variant)              # lane-high only / lane-low only; stores interleaved with multiplies
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:300], b[:300]), ref[:300]), variant
     ctx.set_option("br_variant", 7)                        # 2L-waves-per-gate (latency) kernel, forced for every launch size
     for sl in (16, 5, 4096):                               # sliced, ragged, whole rotation in one launch
@@ -588,6 +608,8 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert ctx.kernel_variant == "generic-radix2"
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
     ctx.force_generic(False)
+    with pytest.raises(ia.IeacheError):
+        ctx.set_option("br_variant", 11)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("br_slice", 4097)
     with pytest.raises(ia.IeacheError):
