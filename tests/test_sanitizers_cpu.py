@@ -21,10 +21,10 @@ def test_host_code_clean_under_asan_ubsan(tmp_path):
     objs.append(str(o))
     for src in ("tfhe_oracle.c", "cloud_oracle.c"):
         o = tmp_path / (src + ".o")
-        subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined",
+        subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fopenmp", "-fsanitize=address,undefined",
                                "-fno-sanitize-recover=undefined", "-c", os.path.join(ROOT, "oracle", src), "-o", str(o)])
         objs.append(str(o))
-    subprocess.check_call(["g++", "-fsanitize=address,undefined"] + objs + ["-o", str(exe), "-lm"])
+    subprocess.check_call(["g++", "-fsanitize=address,undefined", "-fopenmp"] + objs + ["-o", str(exe), "-lm"])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([str(exe), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=300)
