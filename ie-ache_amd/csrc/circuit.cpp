@@ -312,6 +312,7 @@ int32_t circuit_n_inputs(int32_t kind, int32_t bits) {
         case CIRC_ADD_KS:
         case CIRC_SUB_KS:
         case CIRC_RSUB_KS:
+        case CIRC_MUL_WALLACE:
             return 2 * bits + 32;
     }
     return -1;
@@ -333,6 +334,7 @@ int32_t circuit_n_outputs(int32_t kind, int32_t bits) {
         case CIRC_RSUB_KS:
             return bits;
         case CIRC_MUL:
+        case CIRC_MUL_WALLACE:
             return 2 * bits;
     }
     return -1;
@@ -411,6 +413,54 @@ static Word kogge_stone_add(CircuitBuilder& b, const Word& x, const Word& y, Ref
     return sum;
 }
 
+// A * B by carry-save reduction (see CIRC_MUL_WALLACE).  Full adder on XOR/AND only:
+//   t = x ^ y ; sum = t ^ z ; carry = (x & y) ^ (z & t)      ((x & y) and (z & t) are never both 1)
+static Word wallace_mul(CircuitBuilder& b, const Word& A, const Word& B) {
+    const int n = (int)A.size(), W = 2 * n;
+    std::vector<std::vector<Ref>> col(W);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) col[i + j].push_back(b.AND(A[j], B[i]));
+    // Dadda's schedule: heights 2, 3, 4, 6, 9, 13, 19, 28, ... (d_{j+1} = floor(1.5 d_j)); each stage reduces every
+    // column just enough to meet the next smaller height, counting the carries that arrive from the column
+    // below in the same stage -- so no carry ripples from stage to stage and 32 rows take 8 stages
+    std::vector<size_t> heights{2};
+    size_t tallest = 0;
+    for (const auto& cc : col) tallest = std::max(tallest, cc.size());
+    while (heights.back() < tallest) heights.push_back(heights.back() * 3 / 2);
+    for (int stage = (int)heights.size() - 2; stage >= 0; stage--) {
+        const size_t d = heights[stage];
+        std::vector<std::vector<Ref>> next(W);
+        for (int c = 0; c < W; c++) {
+            const std::vector<Ref>& cur = col[c];
+            size_t q = 0, total = cur.size() + next[c].size();  // next[c] already holds this stage's carries from column c-1
+            while (total > d) {
+                if (total == d + 1) {  // half adder
+                    const Ref x = cur[q], y = cur[q + 1];
+                    q += 2;
+                    next[c].push_back(b.XOR(x, y));
+                    if (c + 1 < W) next[c + 1].push_back(b.AND(x, y));
+                    total -= 1;
+                } else {               // full adder
+                    const Ref x = cur[q], y = cur[q + 1], z = cur[q + 2];
+                    q += 3;
+                    const Ref t = b.XOR(x, y);
+                    next[c].push_back(b.XOR(t, z));
+                    if (c + 1 < W) next[c + 1].push_back(b.XOR(b.AND(x, y), b.AND(z, t)));  // the top column's carry is 2^(2n): dropped
+                    total -= 2;
+                }
+            }
+            for (; q < cur.size(); q++) next[c].push_back(cur[q]);
+        }
+        col.swap(next);
+    }
+    Word x(W), y(W);
+    for (int c = 0; c < W; c++) {
+        x[c] = col[c].size() > 0 ? col[c][0] : CircuitBuilder::constant(0);
+        y[c] = col[c].size() > 1 ? col[c][1] : CircuitBuilder::constant(0);
+    }
+    return kogge_stone_add(b, x, y, CircuitBuilder::constant(0));
+}
+
 // One branch of main() (cloud.c:870-2718) on symbolic operands: `bits`-wide A and B (a multiple
 // of 32 except for the generalised adders), carry = ciphertextcarry1.  Returns the value samples
 // LSB first, or an empty word for an unsupported (kind, bits).
@@ -436,6 +486,8 @@ static Word build_stage(CircuitBuilder& b, int32_t kind, int32_t bits, const Wor
             CircuitBuilder::NOT(na, A, bits);
             return kogge_stone_add(b, B, na, CircuitBuilder::constant(1));
         }
+        case CIRC_MUL_WALLACE:
+            return wallace_mul(b, A, B);
         case CIRC_MUL:
             if (bits == 32) {  // cloud.c:2655-2718
                 Word r1 = b.fresh(), r2 = b.fresh();
@@ -491,6 +543,7 @@ static const char* stage_name(int32_t kind) {
         case CIRC_ADD_KS: return "add_ks";
         case CIRC_SUB_KS: return "sub_ks";
         case CIRC_RSUB_KS: return "rsub_ks";
+        case CIRC_MUL_WALLACE: return "mul_wallace";
     }
     return "?";
 }
@@ -499,14 +552,16 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool
     if (bits < 1 || bits > 256) return false;
     const int32_t n_in = circuit_n_inputs(kind, bits);
     if (n_in < 0) return false;
-    CircuitBuilder b(n_in, fold);
+    // the carry-save multiplier is built with folding on: it is opt-in and not the reference's gate list
+    // anyway, and its final adder sees constant-zero operands in the outer columns
+    CircuitBuilder b(n_in, fold || kind == CIRC_MUL_WALLACE);
     const Word A = b.input_word(0, bits), B = b.input_word(bits, bits);
     const Word carry1 = b.input_word(2 * bits, 32);  // ciphertextcarry1
     Word result;
     std::string name;
     int32_t k1, k2;
     bool flip;
-    bool has_mul = kind == CIRC_MUL;
+    bool has_mul = kind == CIRC_MUL || kind == CIRC_MUL_WALLACE;
     int32_t sched_bits = bits;
     if (decode_chain(kind, &k1, &k2, &flip)) {
         // Two ./cloud runs of compute() / compute_final() (dragonfly_cipher_cloud.py:1219-1327) as
@@ -529,7 +584,7 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool
         has_mul = k1 == CIRC_MUL || k2 == CIRC_MUL;
         if (k2 == CIRC_MUL) sched_bits = w2;  // the wider multiplier decides the schedule below
     } else {
-        if (kind == CIRC_MUL && bits != 32 && bits != 64 && bits != 128) return false;
+        if ((kind == CIRC_MUL || kind == CIRC_MUL_WALLACE) && bits != 32 && bits != 64 && bits != 128) return false;
         result = build_stage(b, kind, bits, A, B, carry1);
         name = stage_name(kind);
     }
@@ -544,6 +599,10 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool
     if (force && std::string(force) == "balanced") use_balanced = balanced;
     *out = finalize_circuit(name + std::to_string(bits) + (fold ? "_folded" : ""), b, result, use_balanced);
     out->n_reference_bootstraps = b.n_requested();
+    if (kind == CIRC_MUL_WALLACE) {  // what cloud.c performs for the same product
+        Circuit ref;
+        if (build_circuit(CIRC_MUL, bits, &ref, false, false)) out->n_reference_bootstraps = ref.n_bootstraps;
+    }
     return true;
 }
 

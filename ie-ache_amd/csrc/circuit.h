@@ -139,6 +139,12 @@ enum CircuitKind : int32_t {
     CIRC_ADD_KS = 6,
     CIRC_SUB_KS = 7,
     CIRC_RSUB_KS = 8,
+    // The multiplier counterpart of the Kogge-Stone adders (opt-in, same decrypted product, NOT the
+    // reference's ciphertext): all bits*bits partial products at once, column-wise carry-save (Wallace)
+    // reduction with XOR/AND-only full adders, one Kogge-Stone addition of the last two rows.  32 bits:
+    // 32 levels instead of mul32's 255 and fewer bootstraps -- for single expressions, where depth is
+    // what a level-batched evaluator pays for (cloud.c:115-218 is a 32-round ripple accumulate).
+    CIRC_MUL_WALLACE = 9,
     // any two operators chained as compute_final() does
     // (Cloud/dragonfly_cipher_cloud.py:1300-1327), fused into one DAG: stage 1 = k1(A, B),
     // stage 2 = k2(op1, op2) with (op1, op2) = (answer, C) when flip (cloud.data = answer | C,

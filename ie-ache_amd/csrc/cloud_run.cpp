@@ -188,6 +188,9 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
     if (const char* adder = getenv("IEACHE_ADDER")) {
         if (std::string(adder) == "kogge-stone" && kind >= CIRC_ADD && kind <= CIRC_RSUB) kind += CIRC_ADD_KS - CIRC_ADD;
     }
+    if (const char* mult = getenv("IEACHE_MULTIPLIER")) {  // opt-in carry-save multiplier: 32 levels instead of 255 at 32 bits
+        if (std::string(mult) == "wallace" && kind == CIRC_MUL) kind = CIRC_MUL_WALLACE;
+    }
     // Opt-in constant folding (SURVEY App. C note): fewer bootstraps, same decrypted answer, not the
     // reference's ciphertext bits
     const char* fold_env = getenv("IEACHE_FOLD");
@@ -210,7 +213,7 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
     eval_circuit_host(*eval, circ, 1, in.data(), out.data(), &st);
     const double get_time = now_s() - t0;
     fprintf(log, "Computation Time: %lf[sec]\n", get_time);
-    if (kind == CIRC_MUL) {  // cloud.c:2467-2471
+    if (kind == CIRC_MUL || kind == CIRC_MUL_WALLACE) {  // cloud.c:2467-2471
         FILE* t_file = io.stats_path.empty() ? nullptr : fopen(io.stats_path.c_str(), "a");
         if (t_file) {
             fprintf(t_file, "%lf\n", get_time);

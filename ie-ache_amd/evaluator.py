@@ -15,6 +15,7 @@ _LIB = None
 
 CIRC_ADD, CIRC_SUB, CIRC_RSUB, CIRC_MUL, CIRC_MULADD = 1, 2, 3, 4, 5
 CIRC_ADD_KS, CIRC_SUB_KS, CIRC_RSUB_KS = 6, 7, 8  # Kogge-Stone variants (decrypt-identical, not bit-identical)
+CIRC_MUL_WALLACE = 9  # carry-save multiplier (decrypt-identical, not bit-identical)
 GATE_AND, GATE_XOR, GATE_OR, GATE_NAND, GATE_MUX = 0, 1, 2, 3, 4
 
 

@@ -21,6 +21,11 @@ assert run("32-bit A+B (kogge-stone)", 1, 32, 123456789, 987654321, {"IEACHE_ADD
 assert run("32-bit A-B", 2, 32, 987654321, 123456789) == 987654321 - 123456789
 assert run("32-bit A*B", 3, 32, 123456789, 987654321) == 123456789 * 987654321
 assert run("64-bit A*B", 3, 64, 2**62 + 12345, 2**61 + 777) == (2**62 + 12345) * (2**61 + 777)
+W = {"IEACHE_MULTIPLIER": "wallace"}
+assert run("32-bit A*B (carry-save)", 3, 32, 123456789, 987654321, W) == 123456789 * 987654321
+assert run("64-bit A*B (carry-save)", 3, 64, 2**62 + 12345, 2**61 + 777, W) == (2**62 + 12345) * (2**61 + 777)
+assert run("128-bit A*B", 3, 128, 2**126 + 12345, 2**125 + 777) == (2**126 + 12345) * (2**125 + 777)
+assert run("128-bit A*B (carry-save)", 3, 128, 2**126 + 12345, 2**125 + 777, W) == (2**126 + 12345) * (2**125 + 777)
 # cold: the `cloud` executable as the reference runs it (key load + upload + spectrum transform included)
 tools.alice(d, 0, 32, 5, seed=3); tools.alice(d, 0, 32, 7, seed=4, append=True)
 open(os.path.join(d, "operator.txt"), "w").write("1")

@@ -155,8 +155,28 @@ def test_constant_folded_circuits(ia):
     assert ia.circuit_info(4, 32, fold=True).bootstraps == 7568  # regression pin: 11 264 in the reference
 
 
+@pytest.mark.parametrize("bits", [32, 64, 128])
+def test_carry_save_multiplier_plaintext(ia, bits):
+    """Opt-in CIRC_MUL_WALLACE: the same product as cloud.c's shift-add multipliers from a Dadda carry-save tree and
+    one Kogge-Stone addition -- XOR/AND only, a fraction of the depth, fewer bootstraps."""
+    from ieache_amd.tools import int_to_bits, bits_to_int
+    rng = np.random.default_rng(2000 + bits)
+    info, ref = ia.circuit_info(ia.CIRC_MUL_WALLACE, bits), ia.circuit_info(ia.CIRC_MUL, bits)
+    assert info.n_inputs == ref.n_inputs and info.n_outputs == ref.n_outputs == 2 * bits
+    assert info.reference_bootstraps == ref.bootstraps and info.bootstraps < 0.85 * ref.bootstraps
+    assert info.depth <= {32: 40, 64: 46, 128: 54}[bits] and info.n_and + info.n_xor == info.bootstraps
+    m = 1 << bits
+    cases = [(0, 0), (1, m - 1), (m - 1, m - 1), (1 << (bits - 2), 1 << (bits - 2)), (m - 1, 0)]
+    cases += [(int.from_bytes(rng.bytes(bits // 8), "little"), int.from_bytes(rng.bytes(bits // 8), "little")) for _ in range(5)]
+    for a, b in cases:
+        x = np.zeros(info.n_inputs, dtype=np.uint8)
+        x[:bits], x[bits:2 * bits] = int_to_bits(a, bits), int_to_bits(b, bits)
+        x[2 * bits:] = rng.integers(0, 2, size=32)  # the carry word plays no part in this circuit
+        assert bits_to_int(ia.circuit_simulate(ia.CIRC_MUL_WALLACE, bits, x)) == a * b
+
+
 def test_unsupported_circuits_rejected(ia):
-    bad = [(4, 256), (4, 16), (5, 16), (5, 256), (9, 32), (1, 0), (1, 257), (64, 32),
+    bad = [(4, 256), (4, 16), (5, 16), (5, 256), (9, 16), (9, 256), (10, 32), (1, 0), (1, 257), (64, 32),
            (ia.circ_chain(4, 4), 128),   # stage 2 would be a 256-bit MUL: cloud.c:860-864 exits 126
            (ia.circ_chain(1, 4), 256), (ia.circ_chain(4, 1), 48)]
     for kind, bits in bad:

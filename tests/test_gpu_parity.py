@@ -653,6 +653,38 @@ def test_kogge_stone_adders_decrypt_identically(ia, gpu_ctx):
         assert [bits_to_int(d) for d in kb.dec(out)] == [f(a, b) & 0xFFFFFFFF for a, b in vals]
 
 
+def test_carry_save_multiplier_decrypts_identically(ia, gpu_ctx, tmp_path):
+    """Opt-in CIRC_MUL_WALLACE / IEACHE_MULTIPLIER=wallace: same plaintext as the reference's shift-add multipliers,
+    37 / 43 levels instead of 255 / 449."""
+    kb, ctx = gpu_ctx(4, 1024)
+    from ieache_amd.tools import bits_to_int
+    for bits, levels in ((32, 37), (64, 43)):
+        m = 1 << bits
+        vals = [(m - 1, m - 1), (0xDEADBEEF % m, 0x12345678), (0, 12345), (1 << (bits - 2), 1 << (bits - 2))]
+        inp = _inputs(kb, ia.CIRC_MUL_WALLACE, bits, vals, 27)
+        st = ia.Stats()
+        out = ctx.eval_batch(ia.CIRC_MUL_WALLACE, bits, inp, st)
+        info = ia.circuit_info(ia.CIRC_MUL_WALLACE, bits)
+        assert st.levels == info.depth == levels and st.bootstraps == info.bootstraps * len(vals)
+        assert [bits_to_int(d) for d in kb.dec(out)] == [a * b for a, b in vals]
+        if bits == 32:
+            assert np.array_equal(kb.dec(out), kb.dec(ctx.eval_batch(ia.CIRC_MUL, bits, inp)))
+    # through the process contract
+    from ieache_amd import tools
+    p = ia.default_params().copy(n=6, N=64)
+    tools.keygen_files(tmp_path, p)
+    os.environ["IEACHE_MULTIPLIER"] = "wallace"
+    try:
+        rc, size, ok = _run_file_contract(ia, tmp_path, 4, 3, 64, 0xFEDCBA9876543210, 0, 0x0F1E2D3C4B5A6978, 2)
+    finally:
+        del os.environ["IEACHE_MULTIPLIER"]
+    assert rc == 0 and ok
+    code, bit_size, words = tools.verif(tmp_path)
+    assert (code, bit_size) == (2, 128)
+    assert sum(w << (32 * i) for i, w in enumerate(words[:4])) == 0xFEDCBA9876543210 * 0x0F1E2D3C4B5A6978
+    assert (tmp_path / "averagestandard.txt").exists()
+
+
 def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
     """A wider bit-exact sweep at n=630, N=1024: random gate types and operands, including
     operands that are themselves bootstrapped outputs and NOT-ed inputs (the oracle takes ~0.4 s/gate)."""
