@@ -92,6 +92,16 @@ void to_stats(const EvalStats& s, ieache_stats* o) {
     o->levels = s.levels;
     o->chunks = s.chunks;
 }
+// A kernel dereferencing a host or stray address faults the GPU (and can take the node's other GPUs with it), so
+// the device-pointer entry points refuse anything the runtime does not know as device-accessible memory.
+void require_device_pointer(const void* ptr, const char* name) {
+    hipPointerAttribute_t attr;
+    const hipError_t e = hipPointerGetAttributes(&attr, ptr);
+    if (e != hipSuccess) (void)hipGetLastError();
+    if (e != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeUnified))
+        throw std::invalid_argument(std::string(name) + " is not a device pointer");
+}
+
 const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits) {
     auto key = std::make_tuple(kind, bits, ctx->fold);
     auto it = ctx->circuits.find(key);
@@ -172,7 +182,11 @@ ieache_ctx* ieache_ctx_create_device(const ieache_params* p, const int32_t* d_bk
     ieache_ctx* ctx = nullptr;
     const int rc = guarded([&] {
         if (!p || !d_bk || !d_ksk) return fail(IEACHE_EINVAL, "null argument");
-        ctx = make_ctx(to_params(*p), device, [&](Evaluator& e) { e.load_keys_device(d_bk, d_ksk); });
+        ctx = make_ctx(to_params(*p), device, [&](Evaluator& e) {
+            require_device_pointer(d_bk, "d_bk");
+            require_device_pointer(d_ksk, "d_ksk");
+            e.load_keys_device(d_bk, d_ksk);
+        });
         return 0;
     });
     return rc == 0 ? ctx : nullptr;
@@ -280,6 +294,10 @@ int ieache_eval_batch_device(ieache_ctx* ctx, int kind, int bits, size_t batch, 
         if (!ctx || !d_in || !d_out) return fail(IEACHE_EINVAL, "null argument");
         const Circuit* c = get_circuit(ctx, kind, bits);
         if (!c) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
+        if (batch) {
+            require_device_pointer(d_in, "d_in");
+            require_device_pointer(d_out, "d_out");
+        }
         EvalStats st;
         ctx->eval->eval_circuit_device(*c, batch, d_in, d_out, stats ? &st : nullptr);
         to_stats(st, stats);
@@ -292,6 +310,11 @@ int ieache_gates_device(ieache_ctx* ctx, int gate_type, size_t count, const int3
     return guarded([&] {
         if (!ctx || !d_a || !d_b || !d_out) return fail(IEACHE_EINVAL, "null argument");
         if (gate_type < 0 || gate_type > 3) return fail(IEACHE_EINVAL, "unknown gate type");
+        if (count) {
+            require_device_pointer(d_a, "d_a");
+            require_device_pointer(d_b, "d_b");
+            require_device_pointer(d_out, "d_out");
+        }
         EvalStats st;
         ctx->eval->gates_device(gate_type, count, d_a, d_b, d_out, stats ? &st : nullptr);
         to_stats(st, stats);
@@ -340,6 +363,12 @@ int ieache_mux_device(ieache_ctx* ctx, size_t count, const int32_t* d_a, const i
                       int32_t* d_out, ieache_stats* stats) {
     return guarded([&] {
         if (!ctx || !d_a || !d_b || !d_c || !d_out) return fail(IEACHE_EINVAL, "null argument");
+        if (count) {
+            require_device_pointer(d_a, "d_a");
+            require_device_pointer(d_b, "d_b");
+            require_device_pointer(d_c, "d_c");
+            require_device_pointer(d_out, "d_out");
+        }
         EvalStats st;
         ctx->eval->mux_device(count, d_a, d_b, d_c, d_out, stats ? &st : nullptr);
         to_stats(st, stats);

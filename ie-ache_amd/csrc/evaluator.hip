@@ -32,6 +32,8 @@ namespace ieache {
 
 void hip_check(hipError_t e, const char* what, const char* file, int line) {
     if (e == hipSuccess) return;
+    (void)hipGetLastError();  // the runtime keeps a failure as "last error": clear it, or a later, healthy call's
+                              // hipGetLastError() check would report this one again
     char buf[512];
     snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
     throw std::runtime_error(buf);

@@ -17,6 +17,8 @@
  * producing stream (torch.cuda.synchronize(), hipStreamSynchronize) or call
  * ieache_ctx_wait_stream(ctx, producer) first.  Outputs are complete when the
  * call returns (each call synchronises the context's stream before returning).
+ * Device-pointer arguments are checked with hipPointerGetAttributes: a host or
+ * stray address is refused with IEACHE_EINVAL instead of reaching a kernel.
  *
  * Sample layout: one LWE sample = int32[n+1] = a[0..n-1], b (Torus32).  Host
  * buffers are packed rows of n+1; DEVICE buffers are rows of

@@ -634,7 +634,12 @@ def test_edge_cases_empty_batch_and_chunking(ia, gpu_ctx):
     assert np.array_equal(ctx.eval_batch(ia.CIRC_SUB, 32, inp), ref)
     ctx.force_generic(False)
     with pytest.raises(ia.IeacheError):
-        ctx.eval_batch_device(9, 32, 1, 1, 1)  # unknown circuit kind
+        ctx.eval_batch_device(99, 32, 1, 1, 1)  # unknown circuit kind: refused before any pointer is touched
+    with pytest.raises(ia.IeacheError, match="not a device pointer"):
+        ctx.eval_batch_device(ia.CIRC_ADD, 32, 1, 4096, 8192)  # stray addresses never reach a kernel
+    host = np.zeros((1, 96, kb.p.n + 1), np.int32)
+    with pytest.raises(ia.IeacheError, match="not a device pointer"):
+        ctx.eval_batch_device(ia.CIRC_ADD, 32, 1, host.ctypes.data, host.ctypes.data)
 
 
 def test_kogge_stone_adders_decrypt_identically(ia, gpu_ctx):
