@@ -152,6 +152,37 @@ def muladd64_n630():
     print("muladd64_n630.json written in %.0f s" % (time.time() - t0))
 
 
+def mul128_n630():
+    """BASELINE configs[4]'s circuit at the product parameter set: one 128-bit multiplication as cloud.c does it
+    (4 x mul128 + 15 chained adds, cloud.c:2371-2567): 121 184 exact bootstraps at n=630 by the oracle's sequential
+    gate stream in deferred level-parallel mode (~2.5 h on 8 cores)."""
+    import time
+    p = ia.default_params()
+    seed = (314, 1592, 657)
+    k = tools.keygen_raw(p, seed)
+    ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, k["bk"], k["ksk"])
+    a, b, enc_seed = (1 << 126) | 0xFFFFFFFFFFFFFFFFFFFFFFFF, (1 << 127) | 0x123456789ABCDEF0FEDCBA9, 3003
+    S = p.n + 1
+    inb = np.zeros(2 * 128 + 32, dtype=np.uint8)
+    inb[:128], inb[128:256] = tools.int_to_bits(a, 128), tools.int_to_bits(b, 128)
+    inp = tools.encrypt_bits(p, k["lwe_key"], inb, enc_seed)
+    o1 = np.zeros((8, 32, S), np.int32)
+    o2 = np.zeros((8, 32, S), np.int32)
+    o1[:4], o2[:4] = inp[:128].reshape(4, 32, S), inp[128:256].reshape(4, 32, S)
+    t0 = time.time()
+    rc, out = ck.cloud_values(4, 0, 128, o1, o2, inp[256:288], threads=0)
+    assert rc == 0
+    res = np.ascontiguousarray(out[:8].reshape(256, S))
+    assert tools.bits_to_int(tools.decrypt_bits(p, k["lwe_key"], res)) == a * b
+    with open(os.path.join(HERE, "mul128_n630.json"), "w") as f:
+        json.dump({"params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2", "key_seed": list(seed),
+                   "a": a, "b": b, "encrypt_seed": enc_seed, "input_sha256": digest(inp),
+                   "output_sha256": digest(res), "first_sample": res[0].tolist(), "last_sample": res[-1].tolist(),
+                   "bootstraps": int(ck.bootstrap_count), "oracle_seconds": round(time.time() - t0, 1),
+                   "made_by": "tests/golden/make_golden.py mul128_n630 (oracle exact NTT back-end, deferred level-parallel mode)"}, f, indent=0)
+    print("mul128_n630.json written in %.0f s" % (time.time() - t0))
+
+
 def plaintext_kats():
     kats = []
     for bits in (32, 64, 128, 256):
@@ -176,6 +207,8 @@ if __name__ == "__main__":
         mul32_n630()
     elif sys.argv[1:] == ["muladd64_n630"]:  # ~40 min on 8 cores
         muladd64_n630()
+    elif sys.argv[1:] == ["mul128_n630"]:    # ~2.5 h on 8 cores
+        mul128_n630()
     else:
         toy_vectors()
         full_size_kat()
