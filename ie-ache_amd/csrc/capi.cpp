@@ -24,9 +24,10 @@ using namespace ieache;
 
 struct ieache_ctx {
     std::unique_ptr<Evaluator> eval;
-    std::map<std::tuple<int, int, bool>, Circuit> circuits;
+    std::map<std::tuple<int, int, bool, int>, Circuit> circuits;  // (kind, bits, folded, level cap)
     std::string variant;
-    bool fold = false;  // "fold_constants"
+    bool fold = false;           // "fold_constants"
+    bool level_quantum = true;   // "level_quantum": batch-aware level widths for the slack-balanced circuits
 };
 
 namespace {
@@ -102,13 +103,22 @@ void require_device_pointer(const void* ptr, const char* name) {
         throw std::invalid_argument(std::string(name) + " is not a device pointer");
 }
 
-const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits) {
-    auto key = std::make_tuple(kind, bits, ctx->fold);
-    auto it = ctx->circuits.find(key);
-    if (it != ctx->circuits.end()) return &it->second;
-    Circuit c;
-    if (!build_circuit(kind, bits, &c, true, ctx->fold)) return nullptr;
-    return &ctx->circuits.emplace(key, std::move(c)).first->second;
+const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits, size_t batch = 0) {
+    auto fetch = [&](int cap) -> const Circuit* {
+        auto key = std::make_tuple(kind, bits, ctx->fold, cap);
+        auto it = ctx->circuits.find(key);
+        if (it != ctx->circuits.end()) return &it->second;
+        Circuit c;
+        if (!build_circuit(kind, bits, &c, true, ctx->fold, cap)) return nullptr;
+        return &ctx->circuits.emplace(key, std::move(c)).first->second;
+    };
+    const Circuit* base = fetch(0);
+    if (!base || !base->balanced_schedule || !ctx->level_quantum) return base;
+    // slack-balanced circuits: level width chosen so that a level x this batch is a whole number of the
+    // workgroup rounds the GPU holds at once (same DAG, same output bits, another level assignment)
+    const int cap = circuit_level_cap(*base, (int64_t)batch, ctx->eval->resident_gates());
+    const int mean = (int)((base->n_bootstraps + base->depth - 1) / base->depth);
+    return cap > 0 && cap != mean ? fetch(cap) : base;
 }
 // the context is owned by a unique_ptr until it is handed to the caller, so a throwing key load
 // (or Evaluator constructor) releases it
@@ -131,6 +141,8 @@ void fill_info(const Circuit& c, bool fold, ieache_circuit_info* out) {
     out->sched_max_width = c.sched_max_width;
     out->folded = fold ? 1 : 0;
     out->reference_bootstraps = c.n_reference_bootstraps;
+    out->sched_levels = c.n_levels();
+    out->level_cap = 0;
 }
 }  // namespace
 
@@ -236,6 +248,11 @@ int ieache_ctx_wait_stream(ieache_ctx* ctx, void* hip_stream) {
 
 int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(IEACHE_EINVAL, "null argument");
+    if (std::string(name) == "level_quantum") {
+        if (value != 0 && value != 1) return fail(IEACHE_EINVAL, "level_quantum takes 0 or 1");
+        ctx->level_quantum = value != 0;
+        return 0;
+    }
     if (std::string(name) == "fold_constants") {
         if (value != 0 && value != 1) return fail(IEACHE_EINVAL, "fold_constants takes 0 or 1");
         ctx->fold = value != 0;
@@ -262,6 +279,35 @@ int ieache_circuit_info_get_ex(int kind, int bits, int fold_constants, ieache_ci
 }
 int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out) { return ieache_circuit_info_get_ex(kind, bits, 0, out); }
 
+int ieache_circuit_level_cap(int kind, int bits, int fold_constants, int64_t batch, int resident_workgroups) {
+    return guarded([&] {
+        Circuit c;
+        if (!build_circuit(kind, bits, &c, true, fold_constants != 0)) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
+        return (int)circuit_level_cap(c, batch, resident_workgroups);
+    });
+}
+
+int ieache_circuit_info_get_cap(int kind, int bits, int fold_constants, int level_cap, ieache_circuit_info* out) {
+    return guarded([&] {
+        if (!out || level_cap < 0) return fail(IEACHE_EINVAL, "bad argument");
+        Circuit c;
+        if (!build_circuit(kind, bits, &c, true, fold_constants != 0, level_cap)) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
+        fill_info(c, fold_constants != 0, out);
+        out->level_cap = c.balanced_schedule ? level_cap : 0;
+        return 0;
+    });
+}
+
+int ieache_circuit_simulate_cap(int kind, int bits, int fold_constants, int level_cap, const uint8_t* in_bits, uint8_t* out_bits) {
+    return guarded([&] {
+        if (!in_bits || !out_bits || level_cap < 0) return fail(IEACHE_EINVAL, "bad argument");
+        Circuit c;
+        if (!build_circuit(kind, bits, &c, true, fold_constants != 0, level_cap)) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
+        simulate_circuit(c, in_bits, out_bits);
+        return 0;
+    });
+}
+
 int ieache_circuit_simulate_ex(int kind, int bits, int fold_constants, const uint8_t* in_bits, uint8_t* out_bits) {
     return guarded([&] {
         if (!in_bits || !out_bits) return fail(IEACHE_EINVAL, "null argument");
@@ -279,7 +325,7 @@ int ieache_eval_batch(ieache_ctx* ctx, int kind, int bits, size_t batch, const i
                       ieache_stats* stats) {
     return guarded([&] {
         if (!ctx || !in_lwe || !out_lwe) return fail(IEACHE_EINVAL, "null argument");
-        const Circuit* c = get_circuit(ctx, kind, bits);
+        const Circuit* c = get_circuit(ctx, kind, bits, batch);
         if (!c) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
         EvalStats st;
         eval_circuit_host(*ctx->eval, *c, batch, in_lwe, out_lwe, stats ? &st : nullptr);
@@ -292,7 +338,7 @@ int ieache_eval_batch_device(ieache_ctx* ctx, int kind, int bits, size_t batch, 
                              ieache_stats* stats) {
     return guarded([&] {
         if (!ctx || !d_in || !d_out) return fail(IEACHE_EINVAL, "null argument");
-        const Circuit* c = get_circuit(ctx, kind, bits);
+        const Circuit* c = get_circuit(ctx, kind, bits, batch);
         if (!c) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
         if (batch) {
             require_device_pointer(d_in, "d_in");

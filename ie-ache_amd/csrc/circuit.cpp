@@ -144,13 +144,13 @@ void CircuitBuilder::mul128(Word& r, Word& r2, Word& r3, Word& r4, Word& r5, con
     mul_words({&r, &r2, &r3, &r4, &r5}, {&a, &b, &c, &d}, e, carry, nb_bits);
 }
 
-Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const Word& outputs, bool balanced) {
+Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const Word& outputs, bool balanced, int32_t level_cap) {
     Circuit c;
     c.name = name;
     c.n_inputs = b.n_inputs();
     const auto& gates = b.gates();
     const int32_t n_wires = b.n_wires();
-    int32_t depth = 0;
+    int32_t depth = 0;  // ASAP depth; becomes the scheduled depth below when a level cap stretches the schedule
     for (const Gate& g : gates) depth = std::max(depth, g.level);
     c.depth = depth;
     c.n_bootstraps = (int64_t)gates.size();
@@ -177,41 +177,56 @@ Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const
         // with no spare capacity it starves low-ASAP gates and piles them into the first levels.)
         std::vector<int32_t> producer(n_wires, -1);  // wire -> gate index
         for (int32_t i = 0; i < n_gates; i++) producer[gates[i].out] = i;
-        std::vector<int32_t> alap(n_gates, depth);
-        for (int32_t i = n_gates - 1; i >= 0; i--)  // builder order is topological
-            for (const Ref& r : {gates[i].a, gates[i].b})
-                if (r.id >= 0 && producer[r.id] >= 0) alap[producer[r.id]] = std::min(alap[producer[r.id]], alap[i] - 1);
-        const int32_t cap = std::max<int32_t>((n_gates + depth - 1) / depth, 1);
         std::vector<std::vector<int32_t>> users(n_gates);
-        std::vector<int32_t> pending(n_gates, 0);
+        std::vector<int32_t> n_operands(n_gates, 0);
         for (int32_t i = 0; i < n_gates; i++)
             for (const Ref& r : {gates[i].a, gates[i].b})
                 if (r.id >= 0 && producer[r.id] >= 0) {
                     users[producer[r.id]].push_back(i);
-                    pending[i]++;
+                    n_operands[i]++;
                 }
-        auto cmp = [&](int32_t x, int32_t y) { return alap[x] != alap[y] ? alap[x] > alap[y] : x > y; };  // min-heap on ALAP
-        std::priority_queue<int32_t, std::vector<int32_t>, decltype(cmp)> ready(cmp);
-        std::vector<int32_t> next_ready;
-        for (int32_t i = 0; i < n_gates; i++)
-            if (pending[i] == 0) ready.push(i);
-        int32_t done = 0;
-        for (int32_t L = 1; L <= depth; L++) {
-            int32_t taken = 0;
-            next_ready.clear();
-            while (!ready.empty()) {
-                const int32_t g = ready.top();
-                if (alap[g] > L && taken >= cap) break;  // only critical gates may exceed the cap
-                ready.pop();
-                sched[g] = L;
-                taken++;
-                done++;
-                for (int32_t u : users[g])
-                    if (--pending[u] == 0) next_ready.push_back(u);  // usable from the next level on
+        // level_cap > 0 (the caller knows the batch): levels of exactly that many gates, so that a level times
+        // the batch is a whole number of the workgroup rounds the GPU holds at once.  A cap under the mean width
+        // cannot fit the ASAP depth: the schedule is then stretched (more levels, each of them full), which is the
+        // better trade whenever a level is a few rounds wide -- 1.2 rounds cost 2.
+        const int32_t mean = std::max<int32_t>((n_gates + depth - 1) / depth, 1);
+        const int32_t cap = level_cap > 0 ? level_cap : mean;
+        int32_t sched_depth = depth;
+        if (cap < mean) sched_depth = std::max<int32_t>(depth, (n_gates + cap - 1) / cap);
+        for (;; sched_depth += std::max(1, sched_depth / 50)) {
+            std::vector<int32_t> alap(n_gates, sched_depth);
+            for (int32_t i = n_gates - 1; i >= 0; i--)  // builder order is topological
+                for (const Ref& r : {gates[i].a, gates[i].b})
+                    if (r.id >= 0 && producer[r.id] >= 0) alap[producer[r.id]] = std::min(alap[producer[r.id]], alap[i] - 1);
+            std::vector<int32_t> pending = n_operands;
+            auto cmp = [&](int32_t x, int32_t y) { return alap[x] != alap[y] ? alap[x] > alap[y] : x > y; };  // min-heap on ALAP
+            std::priority_queue<int32_t, std::vector<int32_t>, decltype(cmp)> ready(cmp);
+            std::vector<int32_t> next_ready;
+            for (int32_t i = 0; i < n_gates; i++)
+                if (pending[i] == 0) ready.push(i);
+            int32_t done = 0, overflowing = 0;  // levels in which critical gates had to exceed the cap
+            for (int32_t L = 1; L <= sched_depth; L++) {
+                int32_t taken = 0;
+                next_ready.clear();
+                while (!ready.empty()) {
+                    const int32_t g = ready.top();
+                    if (alap[g] > L && taken >= cap) break;  // only critical gates may exceed the cap
+                    if (taken == cap) overflowing++;
+                    ready.pop();
+                    sched[g] = L;
+                    taken++;
+                    done++;
+                    for (int32_t u : users[g])
+                        if (--pending[u] == 0) next_ready.push_back(u);  // usable from the next level on
+                }
+                for (int32_t u : next_ready) ready.push(u);
             }
-            for (int32_t u : next_ready) ready.push(u);
+            // a stretched schedule is accepted once (almost) every level respects the cap: a level over it costs a
+            // whole extra round for a few gates
+            if (done == n_gates && !(level_cap > 0 && cap < mean && overflowing * 50 > sched_depth)) break;
+            if (sched_depth > 4 * depth + n_gates) throw std::logic_error("list scheduling left gates unscheduled");
         }
-        if (done != n_gates) throw std::logic_error("list scheduling left gates unscheduled");
+        depth = sched_depth;  // levels the executor runs; c.depth keeps the ASAP depth
     } else {
         for (int32_t i = 0; i < n_gates; i++) sched[i] = gates[i].level;
     }
@@ -548,7 +563,7 @@ static const char* stage_name(int32_t kind) {
     return "?";
 }
 
-bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool fold) {
+bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool fold, int32_t level_cap) {
     if (bits < 1 || bits > 256) return false;
     const int32_t n_in = circuit_n_inputs(kind, bits);
     if (n_in < 0) return false;
@@ -597,13 +612,35 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool
     bool use_balanced = balanced && has_mul && sched_bits >= 64;
     if (force && std::string(force) == "asap") use_balanced = false;
     if (force && std::string(force) == "balanced") use_balanced = balanced;
-    *out = finalize_circuit(name + std::to_string(bits) + (fold ? "_folded" : ""), b, result, use_balanced);
+    *out = finalize_circuit(name + std::to_string(bits) + (fold ? "_folded" : ""), b, result, use_balanced, use_balanced ? level_cap : 0);
     out->n_reference_bootstraps = b.n_requested();
+    out->balanced_schedule = use_balanced;
     if (kind == CIRC_MUL_WALLACE) {  // what cloud.c performs for the same product
         Circuit ref;
         if (build_circuit(CIRC_MUL, bits, &ref, false, false)) out->n_reference_bootstraps = ref.n_bootstraps;
     }
     return true;
+}
+
+int32_t circuit_level_cap(const Circuit& base, int64_t batch, int32_t resident) {
+    const int64_t n_bootstraps = base.n_bootstraps;
+    const int32_t asap_depth = base.depth;
+    if (!base.balanced_schedule || batch <= 0 || resident <= 0 || asap_depth <= 0 || batch >= resident) return 0;
+    const int64_t mean = (n_bootstraps + asap_depth - 1) / asap_depth;
+    // a circuit whose default schedule already needs levels far above the mean has no slack to flatten
+    // (the carry-save multipliers: their trees are all critical path); stretching it only adds levels
+    if (base.sched_max_width > 2 * mean) return 0;
+    if (mean * batch < resident) return 0;  // under one round per level: narrow levels are the cheap ones
+    int64_t a = resident, b = batch;
+    while (b) {
+        const int64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    const int64_t q = resident / a;  // gates per expression that make one level a whole number of rounds
+    if (q <= 1 || 2 * q > 3 * mean) return 0;  // a quantum far above what the circuit offers per level cannot be filled
+    const int64_t k = std::max<int64_t>(1, (mean + q / 2) / q);
+    return (int32_t)(k * q);
 }
 
 void simulate_circuit(const Circuit& c, const uint8_t* in, uint8_t* out) {

@@ -115,12 +115,15 @@ struct Circuit {
     int32_t depth = 0, max_width = 0;  // ASAP depth / widest ASAP level
     int32_t sched_max_width = 0;       // widest level of the schedule actually executed
     int64_t n_reference_bootstraps = 0;  // what cloud.c performs for this circuit (== n_bootstraps unless folded)
+    bool balanced_schedule = false;      // slack-balanced list schedule (64/128-bit multipliers) rather than ASAP levels
     int32_t n_levels() const { return (int32_t)level_offset.size() - 1; }
 };
 
 // Levelise + allocate slots.  `outputs` are the samples to return per expression.
 // balanced: slack-aware list schedule (default) instead of plain ASAP levels.
-Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const Word& outputs, bool balanced = true);
+// level_cap > 0: gates per level of the balanced schedule (0 = the mean ASAP width); see circuit_level_cap().
+Circuit finalize_circuit(const std::string& name, const CircuitBuilder& b, const Word& outputs, bool balanced = true,
+                         int32_t level_cap = 0);
 
 // ---- the circuits main() dispatches to (cloud.c:870-2718) ----
 // Input sample order for all of them: operand 1 words (32 samples each, LSB
@@ -164,7 +167,12 @@ bool decode_chain(int32_t kind, int32_t* k1, int32_t* k2, bool* flip);
 // balanced=true lets the builder pick the slack-balanced schedule where it saves memory
 // (64/128-bit multipliers); false forces plain ASAP levels.
 // fold=true: constant-folded / gate-shared variant (decrypt-identical, fewer bootstraps; opt-in).
-bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced = true, bool fold = false);
+bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced = true, bool fold = false, int32_t level_cap = 0);
+// Level width (gates per expression) that makes `batch` expressions fill whole rounds of `resident` workgroups:
+// the multiple of resident / gcd(resident, batch) nearest to the circuit's mean width, or 0 (= keep the mean) when
+// a level is under one round anyway or the batch already is a multiple of a round.
+// `base`: the circuit under its default schedule.
+int32_t circuit_level_cap(const Circuit& base, int64_t batch, int32_t resident);
 // number of input / output samples per expression of a circuit kind
 int32_t circuit_n_inputs(int32_t kind, int32_t bits);
 int32_t circuit_n_outputs(int32_t kind, int32_t bits);

@@ -35,6 +35,9 @@ public:
     const Params& params() const { return p_; }
     int device() const { return device_; }
     hipStream_t stream() const { return stream_; }
+    // gate instances the blind-rotation kernel keeps resident at once (one workgroup each, 4 per CU): a launch
+    // takes ceil(gate instances / this) rounds
+    int resident_gates() const { return resident_gates_; }
     // Orders everything launched later on the evaluator's stream after the work queued so far on
     // `producer` (the stream that wrote the key / input buffers handed over as device pointers).
     void wait_for_stream(hipStream_t producer);
@@ -93,6 +96,7 @@ private:
     hipStream_t stream_ = nullptr;
     bool keys_loaded_ = false;
     bool force_generic_ = false;
+    int resident_gates_ = 1024;
     Impl* d_ = nullptr;
 };
 

@@ -542,6 +542,7 @@ void Evaluator::init() {
         int cus = 0;
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         d_->br_wide_max = cus;  // one workgroup of the wide kernel fills a CU
+        resident_gates_ = 4 * cus;  // k_blind_rotate_w2: 2 waves per gate, 256 VGPRs, 35.8 KB of LDS -> 4 workgroups per CU
         if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
     }
     d_->p = p;

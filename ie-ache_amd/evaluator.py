@@ -67,7 +67,8 @@ class Stats(C.Structure):
 class CircuitInfo(C.Structure):
     _fields_ = [("n_inputs", C.c_int32), ("n_outputs", C.c_int32), ("n_slots", C.c_int32), ("depth", C.c_int32),
                 ("max_width", C.c_int32), ("bootstraps", C.c_int64), ("n_and", C.c_int64), ("n_xor", C.c_int64),
-                ("sched_max_width", C.c_int32), ("folded", C.c_int32), ("reference_bootstraps", C.c_int64)]
+                ("sched_max_width", C.c_int32), ("folded", C.c_int32), ("reference_bootstraps", C.c_int64),
+                ("sched_levels", C.c_int32), ("level_cap", C.c_int32)]
 
 
 def library_path():
@@ -124,6 +125,9 @@ def lib():
     L.ieache_ctx_kernel_variant.argtypes = [vp]
     L.ieache_circuit_info_get.argtypes = [C.c_int, C.c_int, C.POINTER(CircuitInfo)]
     L.ieache_circuit_info_get_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(CircuitInfo)]
+    L.ieache_circuit_level_cap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]
+    L.ieache_circuit_info_get_cap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(CircuitInfo)]
+    L.ieache_circuit_simulate_cap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p]
     L.ieache_circuit_simulate.argtypes = [C.c_int, C.c_int, u8p, u8p]
     L.ieache_circuit_simulate_ex.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p]
     L.ieache_ctx_wait_stream.argtypes = [vp, vp]
@@ -178,20 +182,25 @@ def device_count():
     return lib().ieache_device_count()
 
 
-def circuit_info(kind, bits, fold=False):
+def circuit_info(kind, bits, fold=False, level_cap=0):
     info = CircuitInfo()
-    check(lib().ieache_circuit_info_get_ex(kind, bits, int(fold), C.byref(info)))
+    check(lib().ieache_circuit_info_get_cap(kind, bits, int(fold), int(level_cap), C.byref(info)))
     return info
 
 
-def circuit_simulate(kind, bits, in_bits, fold=False):
+def circuit_level_cap(kind, bits, batch, resident_workgroups=1024, fold=False):
+    """Level width a context picks for `batch` expressions ("level_quantum"); 0 = the default schedule."""
+    return check(lib().ieache_circuit_level_cap(kind, bits, int(fold), int(batch), int(resident_workgroups)))
+
+
+def circuit_simulate(kind, bits, in_bits, fold=False, level_cap=0):
     """Plaintext run of the levelised, slot-allocated circuit (host only)."""
     info = circuit_info(kind, bits, fold)
     in_bits = np.ascontiguousarray(in_bits, dtype=np.uint8)
     assert in_bits.shape == (info.n_inputs,)
     out = np.zeros(info.n_outputs, dtype=np.uint8)
-    check(lib().ieache_circuit_simulate_ex(kind, bits, int(fold), in_bits.ctypes.data_as(C.POINTER(C.c_uint8)),
-                                           out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    check(lib().ieache_circuit_simulate_cap(kind, bits, int(fold), int(level_cap), in_bits.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            out.ctypes.data_as(C.POINTER(C.c_uint8))))
     return out
 
 

@@ -106,6 +106,8 @@ typedef struct ieache_circuit_info {
     int32_t sched_max_width; /* widest level of the slack-balanced schedule the executor runs */
     int32_t folded;          /* 1 when this is the constant-folded variant (see "fold_constants") */
     int64_t reference_bootstraps; /* gates Cloud/cloud.c performs for this circuit; == bootstraps unless folded */
+    int32_t sched_levels;    /* levels the executor runs (== depth unless a level cap stretched the schedule) */
+    int32_t level_cap;       /* the cap this schedule was built with (0 = mean ASAP width) */
 } ieache_circuit_info;
 
 const char* ieache_version(void);
@@ -156,6 +158,9 @@ int ieache_ctx_set_chunk(ieache_ctx* ctx, int64_t gate_instances_per_launch);
 int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
 /* named knobs: "chunk", "force_generic", "ks_sliced_min", "ks_gates", "ks_slice", "ks_batch_min",
  * "br_slice", "br_wide_max", "br_variant" (see csrc/evaluator.h), and
+ * "level_quantum" (0/1, default 1: the slack-balanced circuits -- 64/128-bit multipliers -- get a level
+ * width that makes level x batch a whole number of resident-workgroup rounds; same DAG and output bits, more
+ * levels of exactly-full launches when the batch is small), and
  * "fold_constants" (0/1, default 0, also IEACHE_FOLD=1 for the process contract): build circuits
  * with constant operands folded and repeated gates shared.  cloud.c bootstraps every gate, even
  * `x AND 0` on the zero rows of its shift-add multipliers (SURVEY App. C note); the folded circuit
@@ -173,6 +178,11 @@ const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx);
  * ------------------------------------------------------------------ */
 int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out);
 int ieache_circuit_info_get_ex(int kind, int bits, int fold_constants, ieache_circuit_info* out);
+/* the schedule a context would pick for `batch` expressions on a GPU holding `resident_workgroups` blind rotations
+ * at once (4 per CU; "level_quantum"): level_cap = 0 reproduces ieache_circuit_info_get_ex */
+int ieache_circuit_level_cap(int kind, int bits, int fold_constants, int64_t batch, int resident_workgroups);
+int ieache_circuit_info_get_cap(int kind, int bits, int fold_constants, int level_cap, ieache_circuit_info* out);
+int ieache_circuit_simulate_cap(int kind, int bits, int fold_constants, int level_cap, const uint8_t* in_bits, uint8_t* out_bits);
 /* host buffers: in [batch][n_inputs][n+1], out [batch][n_outputs][n+1] */
 int ieache_eval_batch(ieache_ctx* ctx, int kind, int bits, size_t batch, const int32_t* in_lwe, int32_t* out_lwe,
                       ieache_stats* stats);

@@ -198,6 +198,31 @@ def test_slack_balanced_schedule(ia):
     assert i.sched_max_width == i.max_width == 1056  # mul32 keeps ASAP levels (measured faster, store is small)
 
 
+def test_batch_aware_level_width(ia):
+    """"level_quantum": for the slack-balanced circuits a context picks the level width that makes level x batch a
+    whole number of resident-workgroup rounds (1 024 on an MI355X: 4 per CU).  Same DAG, same outputs; more levels,
+    each exactly full, when the batch is small."""
+    rng = np.random.default_rng(8)
+    assert ia.circuit_level_cap(4, 128, 16) == 64        # 64 x 16 = one round; the mean width 76 would cost two
+    assert ia.circuit_level_cap(5, 64, 128) == 80        # 80 x 128 = ten rounds: what the default schedule already does
+    assert ia.circuit_level_cap(4, 128, 1024) == 0       # a whole round per gate of a level: nothing to quantise
+    assert ia.circuit_level_cap(4, 128, 2) == 0          # under one round per level: narrow levels are the cheap ones
+    assert ia.circuit_level_cap(4, 32, 16) == 0          # ASAP-scheduled circuits keep their levels
+    assert ia.circuit_level_cap(ia.CIRC_MUL_WALLACE, 128, 16) == 0  # no slack to flatten
+    assert ia.circuit_level_cap(4, 64, 100) == 0         # quantum 256 is beyond what a level offers
+    base, capped = ia.circuit_info(4, 64), ia.circuit_info(4, 64, level_cap=64)
+    assert (base.sched_levels, base.level_cap) == (449, 0) and capped.level_cap == 64
+    assert capped.bootstraps == base.bootstraps and capped.depth == base.depth == 449
+    assert -(-base.bootstraps // 64) <= capped.sched_levels <= 1.1 * base.bootstraps / 64
+    assert capped.sched_max_width <= 70 and capped.n_slots <= base.n_slots
+    for _ in range(3):
+        x = rng.integers(0, 2, size=base.n_inputs, dtype=np.uint8)
+        assert np.array_equal(ia.circuit_simulate(4, 64, x), ia.circuit_simulate(4, 64, x, level_cap=64))
+    x = rng.integers(0, 2, size=ia.circuit_info(5, 64).n_inputs, dtype=np.uint8)
+    assert np.array_equal(ia.circuit_simulate(5, 64, x), ia.circuit_simulate(5, 64, x, level_cap=64))
+    assert ia.circuit_info(4, 32, level_cap=64).sched_levels == 255  # ignored where the schedule is ASAP
+
+
 @pytest.mark.parametrize("bits", [1, 5, 16, 32, 64, 256])
 def test_kogge_stone_adders_plaintext(ia, bits):
     """XOR/AND-only parallel-prefix adders decrypt like the ripple ones."""

@@ -690,6 +690,30 @@ def test_carry_save_multiplier_decrypts_identically(ia, gpu_ctx, tmp_path):
     assert (tmp_path / "averagestandard.txt").exists()
 
 
+def test_batch_aware_level_width_same_bits(ia, gpu_ctx):
+    """"level_quantum" re-levels the 64/128-bit multipliers for the batch at hand (here 16 expressions: levels of 64 gates
+    = exactly one round of 1 024 resident workgroups); the DAG is the same, so every output sample is."""
+    kb, ctx = gpu_ctx(4, 1024)
+    rng = np.random.default_rng(16)
+    vals = [(int.from_bytes(rng.bytes(8), "little"), int.from_bytes(rng.bytes(8), "little")) for _ in range(16)]
+    inp = _inputs(kb, 4, 64, vals, 33)
+    resident = 4 * 256
+    cap = ia.circuit_level_cap(4, 64, 16, resident)
+    assert cap == 64
+    st = ia.Stats()
+    out = ctx.eval_batch(4, 64, inp, st)
+    assert st.levels == ia.circuit_info(4, 64, level_cap=cap).sched_levels > 449 and st.bootstraps == 16 * 35296
+    ctx.set_option("level_quantum", 0)
+    try:
+        st0 = ia.Stats()
+        ref = ctx.eval_batch(4, 64, inp, st0)
+    finally:
+        ctx.set_option("level_quantum", 1)
+    assert st0.levels == 449 and np.array_equal(out, ref)
+    from ieache_amd.tools import bits_to_int
+    assert [bits_to_int(d) for d in kb.dec(out)] == [a * b for a, b in vals]
+
+
 def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
     """A wider bit-exact sweep at n=630, N=1024: random gate types and operands, including
     operands that are themselves bootstrapped outputs and NOT-ed inputs (the oracle takes ~0.4 s/gate)."""
