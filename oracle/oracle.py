@@ -29,6 +29,10 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
+        # idle OpenMP threads sleep instead of spinning: on a box whose CPU quota is below its thread count
+        # spinning waiters starve the workers at every level barrier (read by libgomp when it is loaded)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        os.environ.setdefault("GOMP_SPINCOUNT", "0")
         path = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()

@@ -18,6 +18,7 @@
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -760,7 +761,7 @@ int64_t orc_defer_run(orc_cloudkey *ck, int nthreads)
     for (int32_t l = 0; l <= max_level; l++) {
         const size_t lo = first[l], hi = first[l + 1];
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : omp_get_max_threads())
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : orc_max_threads())
 #endif
         for (size_t q = lo; q < hi; q++) {
             const orc_op *op = &t->ops[order[q]];
@@ -795,16 +796,46 @@ void orc_gates_batch(const orc_cloudkey *ck, int32_t type, size_t count, int32_t
 {
     const size_t S = (size_t)ck->p.n + 1;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : omp_get_max_threads())
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : orc_max_threads())
 #endif
     for (size_t i = 0; i < count; i++) run_op(ck, type, out + i * S, a + i * S, b + i * S, NULL);
     (void)nthreads;
 }
 
+/* Threads worth starting: what OpenMP would use, capped by the CPU time this process is actually allowed
+ * (cgroup v2 cpu.max, cgroup v1 cfs quota, the affinity mask) and by ORC_THREADS.  A GPU box hands a one-GPU job
+ * 16 CPUs' worth of a 128-thread host: 128 spinning threads on a 16-CPU quota crawl at every level barrier. */
 int orc_max_threads(void)
 {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    long n = omp_get_num_procs();
+    const char *env = getenv("ORC_THREADS");
+    if (env && atol(env) > 0) return (int)atol(env);
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char quota[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            long q = (atol(quota) + period - 1) / period;
+            if (q >= 1 && q < n) n = q;
+        }
+        fclose(f);
+    } else {
+        long quota = -1, period = 0;
+        f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+        if (f) {
+            if (fscanf(f, "%ld", &quota) != 1) quota = -1;
+            fclose(f);
+        }
+        f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (f) {
+            if (fscanf(f, "%ld", &period) != 1) period = 0;
+            fclose(f);
+        }
+        if (quota > 0 && period > 0 && (quota + period - 1) / period < n) n = (quota + period - 1) / period;
+    }
+    if (n > 32) n = 32; /* the levels of these circuits are a few dozen gates wide: more threads only wait */
+    return n < 1 ? 1 : (int)n;
 #else
     return 1;
 #endif
