@@ -6,8 +6,13 @@
 
 #include <cerrno>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace ieache {
 
@@ -152,6 +157,26 @@ static void add_mul_binary_key(int32_t N, uint32_t* b, const Torus32* a, const i
     }
 }
 
+// Threads for the two key-generation loops: OpenMP's default is every hardware thread of the host, but a
+// container is often allowed far less CPU time than that (cgroup cpu.max), and hundreds of threads on a
+// 16-CPU share only contend.
+static int host_threads() {
+    int n = 1;
+#ifdef _OPENMP
+    n = omp_get_num_procs();
+#endif
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = (atol(quota) + period - 1) / period;
+            if (q >= 1 && q < n) n = (int)q;
+        }
+        fclose(f);
+    }
+    return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+
 void keygen(const Params& p, const uint32_t* seed_words, int nseed, SecretKeyData* out,
             bool with_cloud) {
     out->p = p;
@@ -168,11 +193,13 @@ void keygen(const Params& p, const uint32_t* seed_words, int nseed, SecretKeyDat
     out->cloud.ksk.clear();
     if (!with_cloud) return;
 
+    const int n_threads = host_threads();
+    (void)n_threads;
     const int32_t N = p.N, k = p.k, l = p.l, kpl = p.kpl();
     // Bootstrapping key: BK_i = TGSW_enc(lwe_key[i]) under the TLWE key.
     // One RNG stream per i so the loop can run in any order / in parallel.
     out->cloud.bk.assign(p.bk_count(), 0);
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
     for (int32_t i = 0; i < p.n; i++) {
         Rng rng = make_rng(1 + (uint64_t)i);
         Torus32* bki = out->cloud.bk.data() + (size_t)i * kpl * (k + 1) * N;
@@ -196,7 +223,7 @@ void keygen(const Params& p, const uint32_t* seed_words, int nseed, SecretKeyDat
     // Key-switch key: KSK[i][j][d] = LWE_enc(d * tlwe_key[i] / base^(j+1)) under the n-key
     const int32_t base = p.ks_base(), n = p.n;
     out->cloud.ksk.assign(p.ksk_count(), 0);
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
     for (int32_t i = 0; i < k * N; i++) {
         Rng rng = make_rng((uint64_t)1 << 32 | (uint64_t)i);
         for (int32_t j = 0; j < p.ks_t; j++)
