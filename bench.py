@@ -132,8 +132,9 @@ def cpu_baseline(p, keys, seconds=12.0):
     kind "port": the reference binary cannot be built (libtfhe absent).  `value` is the oracle's
     FP64-FFT back-end, which follows libtfhe's own algorithm, on ONE thread -- how the reference
     effectively runs (its OpenMP pragmas are inert).  `all_cores` is the same back-end with
-    independent gates spread over every host core; the exact-integer
-    back-end used for parity is reported beside them."""
+    independent gates spread over every CPU the job may use (the host's
+    hardware threads, capped by the container's CPU quota); the exact-integer back-end used for
+    parity is reported beside them."""
     from oracle import oracle as O
     from ieache_amd import tools
     ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, keys["bk"], keys["ksk"])
@@ -176,7 +177,9 @@ def cpu_baseline(p, keys, seconds=12.0):
         "sample": "%d AND/XOR gates (n=%d,N=%d) in %.1f s with the oracle's FP64-FFT back-end (libtfhe's algorithm), "
                   "1 thread as the reference runs (its OpenMP pragmas are inert); exact-integer back-end: %.2f gates/s"
                   % (n, p.n, p.N, dt, ne / dte),
-        "all_cores": {"value": count / dta, "cores": cores, "sample": "%d independent AND gates in %.1f s, OpenMP over gates, same back-end" % (count, dta)},
+        "all_cores": {"value": count / dta, "cores": cores,
+                      "sample": "%d independent AND gates in %.1f s, OpenMP over gates on the %d CPUs this job may use "
+                                "(the host's hardware threads capped by its cgroup CPU quota), same back-end" % (count, dta, cores)},
         "real_libtfhe": ("in the loader cache but not timed: %s" % probe) if probe else "unavailable on this host (no libtfhe* in /etc/ld.so.cache = `ldconfig -p | grep tfhe` empty)",
     }
 
