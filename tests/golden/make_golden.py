@@ -183,6 +183,62 @@ def mul128_n630():
     print("mul128_n630.json written in %.0f s" % (time.time() - t0))
 
 
+def misc_n630():
+    """Smaller product-parameter vectors (about 1 500 exact bootstraps, ~6 min on 8 cores): the chained a+b-c at 32 bits
+    (compute() + compute_final(), ADD then SUB), (-A)+B at 64 bits, and bootsOR / bootsNAND / bootsMUX gates."""
+    import time
+    p = ia.default_params()
+    seed = (314, 1592, 657)
+    k = tools.keygen_raw(p, seed)
+    ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, k["bk"], k["ksk"])
+    S = p.n + 1
+    t0 = time.time()
+    out = {"params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2", "key_seed": list(seed)}
+    # a + b - c, 32 bits: IEACHE_CIRC_CHAIN(ADD, SUB, flip) inputs = A, B, carry word, C
+    a, b, c = 0xF0E1D2C3, 0x1F2E3D4C, 0x89ABCDEF
+    inb = np.zeros(32 * 4, dtype=np.uint8)
+    inb[:32], inb[32:64], inb[96:128] = tools.int_to_bits(a, 32), tools.int_to_bits(b, 32), tools.int_to_bits(c, 32)
+    inp = tools.encrypt_bits(p, k["lwe_key"], inb, 3004)
+    o1 = np.zeros((8, 32, S), np.int32)
+    o2 = np.zeros((8, 32, S), np.int32)
+    o1[0], o2[0] = inp[:32], inp[32:64]
+    rc, st1 = ck.cloud_values(1, 0, 32, o1, o2, inp[64:96], threads=0)
+    assert rc == 0
+    C = np.zeros((8, 32, S), np.int32)
+    C[0] = inp[96:128]
+    rc, st2 = ck.cloud_values(2, 0, 32, np.ascontiguousarray(st1[:8]), C, inp[64:96], threads=0)
+    assert rc == 0 and tools.bits_to_int(tools.decrypt_bits(p, k["lwe_key"], st2[0])) == (a + b - c) % (1 << 32)
+    out["addsub32"] = {"a": a, "b": b, "c": c, "encrypt_seed": 3004, "input_sha256": digest(inp),
+                       "output_sha256": digest(np.ascontiguousarray(st2[0])), "first_sample": st2[0][0].tolist()}
+    # (-A) + B at 64 bits = circuit RSUB (operator 1, first operand negative)
+    a, b = 0x0123456789ABCDEF, 0xFEDCBA9876543210
+    inb = np.zeros(64 * 2 + 32, dtype=np.uint8)
+    inb[:64], inb[64:128] = tools.int_to_bits(a, 64), tools.int_to_bits(b, 64)
+    inp = tools.encrypt_bits(p, k["lwe_key"], inb, 3005)
+    o1[:] = 0
+    o2[:] = 0
+    o1[:2], o2[:2] = inp[:64].reshape(2, 32, S), inp[64:128].reshape(2, 32, S)
+    rc, r = ck.cloud_values(1, 1, 64, o1, o2, inp[128:160], threads=0)
+    res = np.ascontiguousarray(r[:2].reshape(64, S))
+    assert rc == 0 and tools.bits_to_int(tools.decrypt_bits(p, k["lwe_key"], res)) == (b - a) % (1 << 64)
+    out["rsub64"] = {"a": a, "b": b, "encrypt_seed": 3005, "input_sha256": digest(inp), "output_sha256": digest(res),
+                     "last_sample": res[-1].tolist()}
+    # gates: OR, NAND, MUX on the four / eight input combinations
+    bits = np.array([[0, 0, 0, 0, 1, 1, 1, 1], [0, 0, 1, 1, 0, 0, 1, 1], [0, 1, 0, 1, 0, 1, 0, 1]], dtype=np.uint8)
+    ga, gb, gc = (tools.encrypt_bits(p, k["lwe_key"], bits[i], 3006 + i) for i in range(3))
+    g_or = ck.gates_batch("or", ga, gb)
+    g_nand = ck.gates_batch("nand", ga, gb)
+    g_mux = np.stack([ck.mux(ga[i], gb[i], gc[i]) for i in range(8)])
+    assert np.array_equal(tools.decrypt_bits(p, k["lwe_key"], g_mux), np.where(bits[0] == 1, bits[1], bits[2]))
+    out["gates"] = {"encrypt_seeds": [3006, 3007, 3008], "or_sha256": digest(g_or), "nand_sha256": digest(g_nand),
+                    "mux_sha256": digest(g_mux), "mux_first_sample": g_mux[0].tolist()}
+    out["oracle_seconds"] = round(time.time() - t0, 1)
+    out["made_by"] = "tests/golden/make_golden.py misc_n630 (oracle exact NTT back-end)"
+    with open(os.path.join(HERE, "misc_n630.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("misc_n630.json written in %.0f s" % (time.time() - t0))
+
+
 def plaintext_kats():
     kats = []
     for bits in (32, 64, 128, 256):
@@ -209,6 +265,8 @@ if __name__ == "__main__":
         muladd64_n630()
     elif sys.argv[1:] == ["mul128_n630"]:    # ~2.5 h on 8 cores
         mul128_n630()
+    elif sys.argv[1:] == ["misc_n630"]:      # ~6 min
+        misc_n630()
     else:
         toy_vectors()
         full_size_kat()

@@ -387,6 +387,56 @@ def test_muladd64_at_product_parameters_matches_golden(ia, gpu_ctx):
     assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == g["output_sha256"]
 
 
+def test_misc_product_parameter_vectors(ia, gpu_ctx):
+    """n=630 vectors for the paths the big goldens do not touch: a chained ADD -> SUB, the (-A)+B branch, OR / NAND / MUX
+    (tests/golden/misc_n630.json, made by the oracle offline)."""
+    import hashlib
+    from ieache_amd.tools import int_to_bits
+    g = json.load(open(os.path.join(G, "misc_n630.json")))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(g["key_seed"]))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    v = g["addsub32"]
+    inb = np.zeros(128, dtype=np.uint8)
+    inb[:32], inb[32:64], inb[96:128] = int_to_bits(v["a"], 32), int_to_bits(v["b"], 32), int_to_bits(v["c"], 32)
+    inp = kb.enc(inb, v["encrypt_seed"])
+    assert sha(inp) == v["input_sha256"]
+    out = ctx.eval_batch(ia.circ_chain(ia.CIRC_ADD, ia.CIRC_SUB), 32, inp[None])[0]
+    assert out[0].tolist() == v["first_sample"] and sha(out) == v["output_sha256"]
+    v = g["rsub64"]
+    inb = np.zeros(160, dtype=np.uint8)
+    inb[:64], inb[64:128] = int_to_bits(v["a"], 64), int_to_bits(v["b"], 64)
+    inp = kb.enc(inb, v["encrypt_seed"])
+    assert sha(inp) == v["input_sha256"]
+    out = ctx.eval_batch(ia.CIRC_RSUB, 64, inp[None])[0]
+    assert out[-1].tolist() == v["last_sample"] and sha(out) == v["output_sha256"]
+    v = g["gates"]
+    bits = np.array([[0, 0, 0, 0, 1, 1, 1, 1], [0, 0, 1, 1, 0, 0, 1, 1], [0, 1, 0, 1, 0, 1, 0, 1]], dtype=np.uint8)
+    ga, gb, gc = (kb.enc(bits[i], v["encrypt_seeds"][i]) for i in range(3))
+    assert sha(ctx.gates(ia.GATE_OR, ga, gb)) == v["or_sha256"]
+    assert sha(ctx.gates(ia.GATE_NAND, ga, gb)) == v["nand_sha256"]
+    mux = ctx.mux(ga, gb, gc)
+    assert mux[0].tolist() == v["mux_first_sample"] and sha(mux) == v["mux_sha256"]
+
+
+def test_mul128_at_product_parameters_matches_golden(ia, gpu_ctx):
+    """BASELINE configs[4]'s circuit at n=630: one 128-bit multiplication (121 184 bootstraps, 1 601 levels) against the
+    oracle's sequential run (tests/golden/mul128_n630.json)."""
+    import hashlib
+    from ieache_amd.tools import bits_to_int, int_to_bits
+    g = json.load(open(os.path.join(G, "mul128_n630.json")))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(g["key_seed"]))
+    inb = np.zeros(2 * 128 + 32, dtype=np.uint8)
+    inb[:128], inb[128:256] = int_to_bits(g["a"], 128), int_to_bits(g["b"], 128)
+    inp = kb.enc(inb, g["encrypt_seed"])
+    assert hashlib.sha256(np.ascontiguousarray(inp).tobytes()).hexdigest() == g["input_sha256"]
+    st = ia.Stats()
+    out = ctx.eval_batch(ia.CIRC_MUL, 128, inp[None], st)[0]
+    assert st.bootstraps == 121184 == g["bootstraps"] and st.levels == 1601
+    assert bits_to_int(kb.dec(out)) == g["a"] * g["b"]
+    assert out[0].tolist() == g["first_sample"] and out[-1].tolist() == g["last_sample"]
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == g["output_sha256"]
+
+
 def test_noise_margin_of_bootstrapped_outputs(ia, gpu_ctx):
     """SURVEY section 7 step 1 at the product parameter set: the phase error of bootstrapped outputs against
     the analytic variance of TFHE gate bootstrapping (Keygen/keygen.c:22-23's set: sigma_bk = 2^-25, sigma_ks =
