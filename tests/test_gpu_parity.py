@@ -935,7 +935,7 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--batch", "48", "--backend", "gloo", "--no-cpu-baseline"]
+           "--batch", "48", "--backend", "gloo", "--no-cpu-baseline", "--mul32-leg", "on", "--mul32-batch", "6"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path,
                        env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-2000:]
@@ -944,4 +944,9 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["batch_per_gpu"] == 48 and out["config"]["parallelism"] == "batch-sharded x2"
-    assert "cpu_baseline" not in out and out["roofline"]["frac"] > 0
+    assert "cpu_baseline" not in out and out["roofline"]["frac"] > 0 and out["roofline"]["bound"] == "fp64_valu"
+    assert out["config"]["collective_backend"] == "gloo" and len(out["config"]["per_rank_gate_ops_per_s"]) == 2
+    # the second leg ran on both ranks too (its passes contain barriers: a rank skipping one would hang the other)
+    m = out["mul32"]
+    assert m["batch_per_gpu"] == 6 and len(m["per_rank_gate_ops_per_s"]) == 2 and m["mul32_per_s"] == out["mul32_per_s"] > 0
+    assert m["folded"]["executed_bootstraps_per_expr"] == 7568 and m["carry_save"]["levels"] == 37
