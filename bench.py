@@ -246,6 +246,13 @@ def timed(torch, dist, world, dev, backend, fn):
 T_START = time.perf_counter()
 
 
+def progress(rank, msg):
+    """One line on stderr per finished leg (stdout carries only the JSON line): a run that is silent for
+    minutes looks hung to whoever is watching it."""
+    if rank == 0:
+        print("[bench %6.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +304,7 @@ def main():
     if args.chunk:
         ctx.set_chunk(args.chunk)
     pmc = pmc_counters(ctx.kernel_variant)
+    progress(rank, "cloud key resident on %d GPU(s), kernel %s" % (world, ctx.kernel_variant))
 
     # ---- primary leg ----
     info, inb, d_in, d_out = make_inputs(ia, tools, torch, ctx, p, lwe_key, kind, bits, batch, rank, dev, 1000)
@@ -309,7 +317,9 @@ def main():
     check_outputs(tools, p, lwe_key, kind, bits, inb, d_out, rank)
 
     stats = ia.Stats()
+    progress(rank, "%s x%d: warm-up done, every expression decrypts; timing %d steps" % (args.workload, batch, args.steps))
     elapsed, per_rank = timed(torch, dist, world, dev, args.backend, lambda: [step(stats) for _ in range(args.steps)])
+    progress(rank, "%s x%d: %.0f gate ops/s" % (args.workload, batch, info.bootstraps * batch * args.steps * world / elapsed))
     del d_in, d_out
 
     # ---- second leg: BASELINE configs[2], the metric's "encrypted 32-bit MUL/sec" ----
@@ -322,6 +332,7 @@ def main():
         m_elapsed, m_per_rank = timed(torch, dist, world, dev, args.backend,
                                       lambda: ctx.eval_batch_device(4, 32, mb, md_in.data_ptr(), md_out.data_ptr(), mst))
         check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)  # all `mb` products, after the timed pass
+        progress(rank, "mul32 x%d: %.2f MUL/s" % (mb, mb * world / m_elapsed))
         folded = None
         if not args.no_folded:
             finfo = ia.circuit_info(4, 32, fold=True)
@@ -331,6 +342,7 @@ def main():
                                  lambda: ctx.eval_batch_device(4, 32, mb, md_in.data_ptr(), md_out.data_ptr(), fst))
             ctx.set_option("fold_constants", 0)
             check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)
+            progress(rank, "mul32 x%d, constants folded: %.2f MUL/s" % (mb, mb * world / f_elapsed))
             folded = {"flag": "fold_constants=1 (IEACHE_FOLD=1): constant operands folded, repeated gates shared; decrypt-identical, "
                               "NOT the reference's ciphertext bits; never the default",
                       "executed_bootstraps_per_expr": int(finfo.bootstraps), "reference_bootstraps_per_expr": int(finfo.reference_bootstraps),
@@ -353,6 +365,7 @@ def main():
             w_elapsed, _ = timed(torch, dist, world, dev, args.backend,
                                  lambda: ctx.eval_batch_device(ia.CIRC_MUL_WALLACE, 32, mb, md_in.data_ptr(), md_out.data_ptr(), wst))
             check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)
+            progress(rank, "mul32 x%d, carry-save multiplier: %.2f MUL/s" % (mb, mb * world / w_elapsed))
             carry_save = {"flag": "IEACHE_CIRC_MUL_WALLACE (IEACHE_MULTIPLIER=wallace): Dadda carry-save tree + Kogge-Stone add; "
                                   "decrypt-identical, NOT the reference's gate sequence; never the default",
                           "executed_bootstraps_per_expr": int(winfo.bootstraps), "reference_bootstraps_per_expr": int(winfo.reference_bootstraps),
