@@ -28,7 +28,8 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 // kernel variant: 0 = LDS transposes, wave-local sync (default; IEACHE_BR_VARIANT overrides); 1 = same with
 // s_memtime diagnostics printed to stderr; 2 = LDS transposes with workgroup barriers; 3 = cross-lane
 // (DPP / v_permlane*_swap) transposes; 4 = 3 with diagnostics; 5 / 6 = only the lane-high / lane-low transpose cross-lane;
-// 10 = forward-transform LDS stores interleaved with the twiddle multiplies that feed them (measured: no gain).
+// 10 = forward-transform LDS stores interleaved with the twiddle multiplies that feed them (measured: no gain);
+// 11 = with round 1's (unneeded) workgroup barrier at the end of every CMux step.
 // All produce identical bits.
 int32_t default_variant();
 // 7 = 2L waves per gate (k_blind_rotate_wide): lower latency per gate, for launches of few gates;
