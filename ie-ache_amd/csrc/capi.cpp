@@ -148,7 +148,7 @@ void fill_info(const Circuit& c, bool fold, ieache_circuit_info* out) {
 
 extern "C" {
 
-const char* ieache_version(void) { return "ieache-amd 0.1 (gfx950)"; }
+const char* ieache_version(void) { return "ieache-amd 0.2 (gfx950)"; }
 const char* ieache_last_error(void) { return g_err.c_str(); }
 const char* ieache_last_key_layout(void) { return last_key_layout().c_str(); }
 
