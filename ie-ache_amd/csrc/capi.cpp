@@ -696,6 +696,8 @@ int64_t ieache_serve(const char* socket_path, const char* cloud_key_path, const 
         if (nbit_key_path) cfg.nbit_key_path = nbit_key_path;
         cfg.device = device;
         cfg.max_requests = max_requests;
+        if (const char* w = getenv("IEACHE_DAEMON_BATCH_WINDOW_MS")) cfg.batch_window_ms = atoi(w) > 0 ? atoi(w) : 0;
+        if (const char* m = getenv("IEACHE_DAEMON_MAX_BATCH")) cfg.max_batch = atoi(m) > 0 ? atoi(m) : 1;
         served = daemon_serve(cfg);
         return 0;
     });

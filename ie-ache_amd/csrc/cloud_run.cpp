@@ -44,38 +44,45 @@ int32_t decrypt_word(const Params& p, const int32_t* key, const Torus32* samples
 }
 }  // namespace
 
-int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* report, int device, FILE* log) {
-    if (!log) log = stdout;
-    const std::string d = dir.empty() ? std::string(".") : dir;
-    auto path = [&](const char* name) { return d + "/" + name; };
-    fprintf(log, "Reading the key...\n");
-    // cloud.c:656-663
-    CloudKeyData ck;
-    std::unique_ptr<Evaluator> owned;
-    if (!shared_eval) load_cloud_key(path("cloud.key"), &ck);
-    SecretKeyData nbit;
-    load_secret_key(path("nbit.key"), &nbit, /*with_cloud=*/false);
-    FileCloser data{fopen(path("cloud.data").c_str(), "rb")};  // cloud.c:703-705
-    if (!data.f) throw CodecError("cannot open cloud.data");
+CloudDirSession::CloudDirSession(const std::string& dir_in, const Params& cloud_params, FILE* log)
+    : dir(dir_in.empty() ? std::string(".") : dir_in) {
+    auto path = [&](const char* name) { return dir + "/" + name; };
+    load_secret_key(path("nbit.key"), &nbit, /*with_cloud=*/false);  // cloud.c:661-663
+    data = fopen(path("cloud.data").c_str(), "rb");                   // cloud.c:703-705
+    if (!data) throw CodecError("cannot open cloud.data");
     int32_t int_op = 0;  // cloud.c:769-773
     {
         std::ifstream in(path("operator.txt"));
         in >> int_op;
     }
-    FileCloser ans{nullptr};
-    CloudRunIO io;
-    io.params = shared_eval ? shared_eval->params() : ck.p;
+    io.params = cloud_params;
     io.nbit = &nbit;
-    io.cloud_data = data.f;
+    io.cloud_data = data;
     io.op = int_op;
-    io.open_answer = [&]() -> FILE* {  // cloud.c:809, after the inputs have been read
-        ans.f = fopen(path("answer.data").c_str(), "wb");
-        if (!ans.f) throw CodecError("cannot create answer.data");
-        return ans.f;
+    io.open_answer = [this]() -> FILE* {  // cloud.c:809, after the inputs have been read
+        answer = fopen((dir + "/answer.data").c_str(), "wb");
+        if (!answer) throw CodecError("cannot create answer.data");
+        return answer;
     };
     io.stats_path = path("averagestandard.txt");
     io.log = log;
-    return cloud_run_io(io, [&]() -> Evaluator* {
+}
+
+CloudDirSession::~CloudDirSession() {
+    if (data) fclose(data);
+    if (answer) fclose(answer);
+}
+
+int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* report, int device, FILE* log) {
+    if (!log) log = stdout;
+    const std::string d = dir.empty() ? std::string(".") : dir;
+    fprintf(log, "Reading the key...\n");
+    // cloud.c:656-663
+    CloudKeyData ck;
+    std::unique_ptr<Evaluator> owned;
+    if (!shared_eval) load_cloud_key(d + "/cloud.key", &ck);
+    CloudDirSession session(d, shared_eval ? shared_eval->params() : ck.p, log);
+    return cloud_run_io(session.io, [&]() -> Evaluator* {
         if (shared_eval) return shared_eval;
         owned.reset(new Evaluator(ck.p, device));
         owned->load_keys_host(ck.bk.data(), ck.ksk.data());
@@ -83,7 +90,10 @@ int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* re
     }, report);
 }
 
-int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_eval, CloudRunReport* report) {
+// Everything main() does before its circuit: inputs, metadata arithmetic in the clear, the 64 metadata samples of
+// answer.data, and the choice of branch.  job->has_circuit says whether a value circuit is to be evaluated;
+// otherwise job->rc (0 or 126) is the whole answer (64-sample answer.data).
+void cloud_prepare(const CloudRunIO& io, CloudJob* job, CloudRunReport* report) {
     FILE* const log = io.log ? io.log : stdout;
     const SecretKeyData& nbit = *io.nbit;
     const Params p = io.params;
@@ -118,6 +128,10 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
 
     struct { FILE* f; } ans{io.open_answer()};  // :809
     if (!ans.f) throw CodecError("no answer sink");
+    job->answer = ans.f;
+    job->params = p;
+    job->rc = 0;
+    job->has_circuit = false;
     int32_t ciphernegative = 0;  // :812-821
     if (int_negative == 1) ciphernegative = 1;
     if (int_negative == 2) ciphernegative = 2;
@@ -156,7 +170,8 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
     }
     if (int_op == 4 && int_bit >= 256) {  // :860-864
         fprintf(log, "Cannot multiply 256 bit number!\n");
-        return 126;
+        job->rc = 126;
+        return;
     }
 
     // dispatch (cloud.c:870, 1194-1196, 1809, 2368)
@@ -177,11 +192,11 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
         kind = CIRC_MUL;
         label = "Multiplication";
     }
-    if (kind == 0) return 0;  // unknown operator: main() falls through, answer.data keeps 64 samples
+    if (kind == 0) return;  // unknown operator: main() falls through, answer.data keeps 64 samples
     fprintf(log, "%d bit %s computation\n", int_bit, label);
     const bool size_ok = kind == CIRC_MUL ? (int_bit == 32 || int_bit == 64 || int_bit == 128)
                                           : (int_bit == 32 || int_bit == 64 || int_bit == 128 || int_bit == 256);
-    if (!size_ok) return 0;  // no branch of main() matches: 64-sample answer.data = failure marker
+    if (!size_ok) return;  // no branch of main() matches: 64-sample answer.data = failure marker
 
     // Opt-in parallel-prefix adders: same decrypted answer, 7x fewer levels for a
     // single expression; NOT the reference's gate sequence, so off unless asked for.
@@ -195,42 +210,84 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
     // reference's ciphertext bits
     const char* fold_env = getenv("IEACHE_FOLD");
     const bool fold = fold_env && fold_env[0] && fold_env[0] != '0';
-    Circuit circ;
-    if (!build_circuit(kind, int_bit, &circ, true, fold)) return 0;
+    const int32_t n_inputs = circuit_n_inputs(kind, int_bit);
+    if (n_inputs < 0) return;
     const int W = int_bit / 32;
     // circuit inputs: operand-1 words, operand-2 words, ciphertextcarry1
-    std::vector<Torus32> in((size_t)circ.n_inputs * S);
-    memcpy(in.data(), opnd1, (size_t)W * WORD * 4);
-    memcpy(in.data() + (size_t)W * WORD, opnd2, (size_t)W * WORD * 4);
-    memcpy(in.data() + (size_t)2 * W * WORD, carry1, WORD * 4);
-    std::vector<Torus32> out(circ.outputs.size() * S);
+    job->in.assign((size_t)n_inputs * S, 0);
+    memcpy(job->in.data(), opnd1, (size_t)W * WORD * 4);
+    memcpy(job->in.data() + (size_t)W * WORD, opnd2, (size_t)W * WORD * 4);
+    memcpy(job->in.data() + (size_t)2 * W * WORD, carry1, WORD * 4);
+    job->carry1.assign(carry1, carry1 + WORD);
+    job->kind = kind;
+    job->int_bit = int_bit;
+    job->fold = fold;
+    job->has_circuit = true;
+}
 
+// What main() does after its circuit: the value words, LSW first, then ciphertextcarry1 as filler up to 9 words
+// (e.g. cloud.c:899-917), the MUL timing log (:2467-2471) and the chatter.
+void cloud_finish(const CloudRunIO& io, const CloudJob& job, const Torus32* out, size_t n_out_samples, double seconds) {
+    FILE* const log = io.log ? io.log : stdout;
+    const int32_t n = job.params.n;
+    const size_t S = (size_t)n + 1;
+    fprintf(log, "Computation Time: %lf[sec]\n", seconds);
+    if (job.kind == CIRC_MUL || job.kind == CIRC_MUL_WALLACE) {  // cloud.c:2467-2471
+        FILE* t_file = io.stats_path.empty() ? nullptr : fopen(io.stats_path.c_str(), "a");
+        if (t_file) {
+            fprintf(t_file, "%lf\n", seconds);
+            fclose(t_file);
+        }
+    }
+    fprintf(log, "writing the answer to file...\n");
+    write_lwe_samples(job.answer, n, n_out_samples, out, S);
+    for (size_t w = n_out_samples / 32; w < 9; w++) write_lwe_samples(job.answer, n, 32, job.carry1.data(), S);
+}
+
+int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_eval, CloudRunReport* report) {
+    FILE* const log = io.log ? io.log : stdout;
+    CloudJob job;
+    cloud_prepare(io, &job, report);
+    if (!job.has_circuit) return job.rc;
+    Circuit circ;
+    if (!build_circuit(job.kind, job.int_bit, &circ, true, job.fold)) return 0;
+    const size_t S = (size_t)job.params.n + 1;
+    std::vector<Torus32> out(circ.outputs.size() * S);
     Evaluator* eval = get_eval();
     if (!eval) throw std::runtime_error("no evaluator");
     fprintf(log, "Doing the homomorphic computation...\n");
     const double t0 = now_s();
     EvalStats st;
-    eval_circuit_host(*eval, circ, 1, in.data(), out.data(), &st);
-    const double get_time = now_s() - t0;
-    fprintf(log, "Computation Time: %lf[sec]\n", get_time);
-    if (kind == CIRC_MUL || kind == CIRC_MUL_WALLACE) {  // cloud.c:2467-2471
-        FILE* t_file = io.stats_path.empty() ? nullptr : fopen(io.stats_path.c_str(), "a");
-        if (t_file) {
-            fprintf(t_file, "%lf\n", get_time);
-            fclose(t_file);
-        }
-    }
-    fprintf(log, "writing the answer to file...\n");
-    // result words LSW first, then ciphertextcarry1 as filler up to 9 words (e.g. :899-917)
-    const size_t n_out_words = circ.outputs.size() / 32;
-    write_lwe_samples(ans.f, n, circ.outputs.size(), out.data(), S);
-    for (size_t w = n_out_words; w < 9; w++) write_lwe_samples(ans.f, n, 32, carry1, S);
+    eval_circuit_host(*eval, circ, 1, job.in.data(), out.data(), &st);
+    cloud_finish(io, job, out.data(), circ.outputs.size(), now_s() - t0);
     if (report) {
-        report->circuit_kind = kind;
+        report->circuit_kind = job.kind;
         report->bootstraps = st.bootstraps;
         report->gpu_ms = st.total_ms;
     }
     return 0;
+}
+
+// Several prepared jobs of one (kind, width, folding) as ONE level-batched evaluation: what makes a resident
+// daemon with many clients use the GPU the way bench.py does.  outs[i] receives job i's value samples.
+void cloud_eval_jobs(Evaluator& eval, const std::vector<CloudJob*>& jobs, std::vector<std::vector<Torus32>>* outs, EvalStats* stats) {
+    if (jobs.empty()) return;
+    const CloudJob& first = *jobs[0];
+    Circuit base, capped;
+    if (!build_circuit(first.kind, first.int_bit, &base, true, first.fold)) throw std::invalid_argument("unsupported circuit");
+    const Circuit* circ = &base;
+    const int32_t cap = circuit_level_cap(base, (int64_t)jobs.size(), eval.resident_gates());
+    if (cap > 0 && build_circuit(first.kind, first.int_bit, &capped, true, first.fold, cap)) circ = &capped;
+    const size_t S = (size_t)first.params.n + 1, n_in = (size_t)circ->n_inputs * S, n_out = circ->outputs.size() * S;
+    std::vector<Torus32> in(jobs.size() * n_in), out(jobs.size() * n_out);
+    for (size_t i = 0; i < jobs.size(); i++) {
+        if (jobs[i]->kind != first.kind || jobs[i]->int_bit != first.int_bit || jobs[i]->fold != first.fold || jobs[i]->in.size() != n_in)
+            throw std::invalid_argument("jobs of different circuits in one batch");
+        memcpy(in.data() + i * n_in, jobs[i]->in.data(), n_in * 4);
+    }
+    eval_circuit_host(eval, *circ, jobs.size(), in.data(), out.data(), stats);
+    outs->resize(jobs.size());
+    for (size_t i = 0; i < jobs.size(); i++) (*outs)[i].assign(out.begin() + i * n_out, out.begin() + (i + 1) * n_out);
 }
 
 void eval_circuit_host(Evaluator& eval, const Circuit& c, size_t batch, const Torus32* in, Torus32* out,

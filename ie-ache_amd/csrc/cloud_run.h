@@ -4,6 +4,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "circuit.h"
 #include "evaluator.h"
@@ -39,6 +40,37 @@ struct CloudRunIO {
     std::string stats_path;              // averagestandard.txt; empty = do not append
     FILE* log = nullptr;                 // stdout chatter; null = stdout
 };
+// The files of one `./cloud` call (nbit.key, cloud.data, operator.txt -> answer.data, averagestandard.txt in `dir`)
+// opened and wired into a CloudRunIO; closes them when it goes.  Not copyable: io points into it.
+struct CloudDirSession {
+    std::string dir;
+    SecretKeyData nbit;
+    FILE* data = nullptr;
+    FILE* answer = nullptr;
+    CloudRunIO io;
+    CloudDirSession(const std::string& dir, const Params& cloud_params, FILE* log);
+    ~CloudDirSession();
+    CloudDirSession(const CloudDirSession&) = delete;
+    CloudDirSession& operator=(const CloudDirSession&) = delete;
+};
+
+// The contract in three steps, so that a daemon holding several requests can evaluate the circuits of all of
+// them as one batch: cloud_prepare (inputs, metadata, the 64 metadata samples, branch choice), evaluation of
+// job.in through circuit (job.kind, job.int_bit, job.fold), cloud_finish (value samples + filler words, logs).
+struct CloudJob {
+    Params params;
+    int rc = 0;                 // what main() returns when has_circuit is false: 0 or 126
+    bool has_circuit = false;
+    int32_t kind = 0, int_bit = 0;
+    bool fold = false;
+    std::vector<Torus32> in;      // circuit inputs, rows of n+1
+    std::vector<Torus32> carry1;  // 32 rows: the filler word of answer.data (cloud.c:901-916)
+    FILE* answer = nullptr;       // io.open_answer()'s sink, metadata already written
+};
+void cloud_prepare(const CloudRunIO& io, CloudJob* job, CloudRunReport* report);
+void cloud_finish(const CloudRunIO& io, const CloudJob& job, const Torus32* out, size_t n_out_samples, double seconds);
+void cloud_eval_jobs(Evaluator& eval, const std::vector<CloudJob*>& jobs, std::vector<std::vector<Torus32>>* outs, EvalStats* stats);
+
 // get_eval is called only if a circuit is actually evaluated.
 int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_eval, CloudRunReport* report);
 

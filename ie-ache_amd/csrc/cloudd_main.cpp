@@ -1,5 +1,8 @@
 // `cloudd`: the Cloud evaluator as a resident-key daemon.
 //   cloudd [--socket PATH] [--key cloud.key] [--nbit nbit.key] [--device N] [--max-requests K]
+//          [--batch-window-ms T] [--max-batch B]
+// --batch-window-ms T: requests arriving within T ms of each other are answered together; those asking for the same
+// circuit are evaluated as one level-batched GPU run (default 0: one request at a time, like the reference).
 // Loads the cloud key once (the reference does it per operator, Cloud/cloud.c:656-663), then
 // serves `cloud` shim / ieache_client_* requests on an AF_UNIX socket until SIGTERM or a
 // shutdown request.  Defaults: ./cloudd.sock, ./cloud.key, nbit.key next to the cloud key.
@@ -28,8 +31,11 @@ int main(int argc, char** argv) {
         else if (a == "--nbit") nbit = need("--nbit");
         else if (a == "--device") device = atoi(need("--device"));
         else if (a == "--max-requests") max_requests = atoll(need("--max-requests"));
+        else if (a == "--batch-window-ms") setenv("IEACHE_DAEMON_BATCH_WINDOW_MS", need("--batch-window-ms"), 1);
+        else if (a == "--max-batch") setenv("IEACHE_DAEMON_MAX_BATCH", need("--max-batch"), 1);
         else {
-            fprintf(stderr, "usage: cloudd [--socket PATH] [--key cloud.key] [--nbit nbit.key] [--device N] [--max-requests K]\n");
+            fprintf(stderr, "usage: cloudd [--socket PATH] [--key cloud.key] [--nbit nbit.key] [--device N] [--max-requests K] "
+                            "[--batch-window-ms T] [--max-batch B]\n");
             return a == "--help" || a == "-h" ? 0 : 2;
         }
     }

@@ -1,8 +1,10 @@
 // Resident-key Cloud daemon and its client (see daemon.h for the wire format).
 #include "daemon.h"
 
+#include <poll.h>
 #include <signal.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <sys/stat.h>
 #include <sys/un.h>
 #include <unistd.h>
@@ -11,9 +13,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <new>
 #include <stdexcept>
+#include <tuple>
 
 #include "../../include/ieache.h"
 #include "cloud_run.h"
@@ -156,14 +160,85 @@ public:
         }
     }
 
+    struct Pending {
+        uint32_t op = 0;
+        std::vector<unsigned char> payload;
+        int32_t rc = 0;
+        std::string log;
+        std::vector<unsigned char> data;
+    };
+
+    // Answers every request of `reqs` (in arrival order for everything with side effects).  The value circuits
+    // of the RUN_DIR / RUN_DATA requests among them are evaluated together: requests that ask for the same
+    // circuit become ONE level-batched evaluation, which is where a GPU's throughput is (a lone 32-bit addition
+    // keeps 2-5 of its 1 024 workgroup slots busy).
+    void handle_batch(std::vector<Pending>& reqs) {
+        std::vector<std::unique_ptr<Run>> runs;
+        for (Pending& r : reqs) {
+            if (r.op == DAEMON_RUN_DIR || r.op == DAEMON_RUN_DATA) {
+                std::unique_ptr<Run> run(new Run);
+                run->req = &r;
+                try {
+                    if (r.op == DAEMON_RUN_DIR) {
+                        const std::string dir(r.payload.begin(), r.payload.end());
+                        if (dir.empty() || dir.find('\0') != std::string::npos) throw std::invalid_argument("bad directory");
+                        // a new session key (dragonfly_public_cloud.py receives cloud.key once per session) is picked up
+                        // here; what was prepared under the old key is evaluated first
+                        const std::string key = dir + "/cloud.key";
+                        const FileId id = FileId::of(key);
+                        if (id.valid && !id.same(key_id_)) {
+                            evaluate(runs);
+                            load_cloud_key_file(key);
+                        }
+                        fprintf(run->log.f, "Reading the key...\n");
+                        run->dir.reset(new CloudDirSession(dir, eval_->params(), run->log.f));
+                        cloud_prepare(run->dir->io, &run->job, nullptr);
+                    } else {
+                        if (!have_nbit_) throw std::invalid_argument("RUN_DATA needs the daemon to hold nbit.key (--nbit)");
+                        if (r.payload.size() < 4) throw std::invalid_argument("RUN_DATA payload too short");
+                        int32_t op = 0;
+                        memcpy(&op, r.payload.data(), 4);
+                        if (r.payload.size() == 4) throw CodecError("cloud.data is empty");
+                        run->in = fmemopen(r.payload.data() + 4, r.payload.size() - 4, "rb");
+                        if (!run->in) throw std::bad_alloc();
+                        run->answer.reset(new MemStream);
+                        run->io.params = eval_->params();
+                        run->io.nbit = &nbit_;
+                        run->io.cloud_data = run->in;
+                        run->io.op = op;
+                        MemStream* ans = run->answer.get();
+                        run->io.open_answer = [ans]() -> FILE* { return ans->f; };
+                        run->io.log = run->log.f;
+                        cloud_prepare(run->io, &run->job, nullptr);
+                    }
+                    run->prepared = true;
+                } catch (...) {
+                    run->fail(std::current_exception());
+                }
+                runs.push_back(std::move(run));
+            } else {
+                evaluate(runs);  // keep the order of everything that is not a pure computation
+                r.rc = handle(r.op, r.payload, &r.log, &r.data);
+            }
+        }
+        evaluate(runs);
+    }
+
+    int64_t batches = 0, batched_requests = 0, largest_batch = 0;
+
     // returns rc; fills log and data
     int32_t handle(uint32_t op, const std::vector<unsigned char>& payload, std::string* log, std::vector<unsigned char>* data) {
         try {
             switch (op) {
                 case DAEMON_PING: *log = std::string(ieache_version()) + ", key " + key_path_; return 0;
                 case DAEMON_SHUTDOWN: *log = "bye"; return 0;
-                case DAEMON_RUN_DIR: return run_dir(std::string(payload.begin(), payload.end()), log);
-                case DAEMON_RUN_DATA: return run_data(payload, log, data);
+                case DAEMON_STATS: {
+                    char buf[160];
+                    snprintf(buf, sizeof buf, "evaluations=%lld batched_requests=%lld largest_batch=%lld", (long long)batches,
+                             (long long)batched_requests, (long long)largest_batch);
+                    *log = buf;
+                    return 0;
+                }
                 default: *log = "unknown request"; return IEACHE_EINVAL;
             }
         } catch (const CodecError& e) {
@@ -194,55 +269,104 @@ private:
         key_path_ = path;
     }
 
-    int32_t run_dir(const std::string& dir, std::string* log) {
-        if (dir.empty() || dir.find('\0') != std::string::npos) throw std::invalid_argument("bad directory");
-        // a new session key (dragonfly_public_cloud.py receives cloud.key once per session) is picked up here
-        const std::string key = dir + "/cloud.key";
-        const FileId id = FileId::of(key);
-        if (id.valid && !id.same(key_id_)) load_cloud_key_file(key);
-        MemStream out;
-        const int rc = cloud_run(dir, eval_.get(), nullptr, cfg_.device, out.f);
-        out.finish();
-        log->assign(out.buf, out.len);
-        return rc;
+    // one RUN_DIR / RUN_DATA request on its way through cloud_prepare -> (batched) evaluation -> cloud_finish
+    struct Run {
+        Pending* req = nullptr;
+        MemStream log;
+        std::unique_ptr<CloudDirSession> dir;  // RUN_DIR
+        FILE* in = nullptr;                    // RUN_DATA: the payload as a stream
+        std::unique_ptr<MemStream> answer;     // RUN_DATA: answer.data in memory
+        CloudRunIO io;
+        CloudJob job;
+        bool prepared = false, failed = false;
+        ~Run() {
+            if (in) fclose(in);
+        }
+        const CloudRunIO& the_io() const { return dir ? dir->io : io; }
+        void fail(std::exception_ptr e) {
+            failed = true;
+            log.finish();
+            req->log.assign(log.buf ? log.buf : "", log.len);
+            try {
+                std::rethrow_exception(e);
+            } catch (const CodecError& x) {
+                req->log += x.what();
+                req->rc = IEACHE_EIO;
+            } catch (const std::bad_alloc&) {
+                req->log += "out of host memory";
+                req->rc = IEACHE_ENOMEM;
+            } catch (const std::invalid_argument& x) {
+                req->log += x.what();
+                req->rc = IEACHE_EINVAL;
+            } catch (const std::exception& x) {
+                req->log += x.what();
+                req->rc = IEACHE_ENODEV;
+            } catch (...) {
+                req->log += "unknown failure";
+                req->rc = IEACHE_ENODEV;
+            }
+        }
+        void reply_ok(int rc) {
+            log.finish();
+            req->log.assign(log.buf ? log.buf : "", log.len);
+            req->rc = rc;
+            if (answer) {
+                answer->finish();
+                req->data.assign(reinterpret_cast<unsigned char*>(answer->buf), reinterpret_cast<unsigned char*>(answer->buf) + answer->len);
+            } else if (dir) {
+                dir.reset();  // closes answer.data before the client is told it is there
+            }
+        }
+    };
+
+    static double now_s() {
+        struct timeval tv;
+        gettimeofday(&tv, nullptr);
+        return tv.tv_sec + tv.tv_usec * 1e-6;
     }
 
-    int32_t run_data(const std::vector<unsigned char>& payload, std::string* log, std::vector<unsigned char>* data) {
-        if (!have_nbit_) throw std::invalid_argument("RUN_DATA needs the daemon to hold nbit.key (--nbit)");
-        if (payload.size() < 4) throw std::invalid_argument("RUN_DATA payload too short");
-        int32_t op = 0;
-        memcpy(&op, payload.data(), 4);
-        FILE* in = fmemopen(const_cast<unsigned char*>(payload.data()) + 4, payload.size() - 4, "rb");
-        if (!in && payload.size() > 4) throw std::bad_alloc();
-        struct InCloser {
-            FILE* f;
-            ~InCloser() {
-                if (f) fclose(f);
+    // evaluates everything prepared so far, grouped by circuit, and fills the replies
+    void evaluate(std::vector<std::unique_ptr<Run>>& runs) {
+        std::map<std::tuple<int32_t, int32_t, bool>, std::vector<Run*>> groups;
+        for (auto& r : runs) {
+            if (r->failed || !r->prepared) continue;
+            if (!r->job.has_circuit) {
+                r->reply_ok(r->job.rc);  // 126, or 0 with the 64-sample failure marker: nothing to evaluate
+                continue;
             }
-        } in_closer{in};
-        if (!in) throw CodecError("cloud.data is empty");
-        MemStream out, answer;
-        CloudRunIO io;
-        io.params = eval_->params();
-        io.nbit = &nbit_;
-        io.cloud_data = in;
-        io.op = op;
-        io.open_answer = [&]() -> FILE* { return answer.f; };
-        io.log = out.f;
-        Evaluator* e = eval_.get();
-        int rc;
-        try {
-            rc = cloud_run_io(io, [e]() { return e; }, nullptr);
-        } catch (...) {
-            out.finish();
-            log->assign(out.buf, out.len);
-            throw;
+            groups[std::make_tuple(r->job.kind, r->job.int_bit, r->job.fold)].push_back(r.get());
         }
-        out.finish();
-        answer.finish();
-        log->assign(out.buf, out.len);
-        data->assign(reinterpret_cast<unsigned char*>(answer.buf), reinterpret_cast<unsigned char*>(answer.buf) + answer.len);
-        return rc;
+        for (auto& g : groups) {
+            std::vector<Run*>& members = g.second;
+            std::vector<CloudJob*> jobs;
+            for (Run* r : members) {
+                jobs.push_back(&r->job);
+                fprintf(r->log.f, "Doing the homomorphic computation...\n");
+            }
+            try {
+                std::vector<std::vector<Torus32>> outs;
+                const double t0 = now_s();
+                cloud_eval_jobs(*eval_, jobs, &outs, nullptr);
+                const double dt = now_s() - t0;
+                batches++;
+                batched_requests += (int64_t)members.size();
+                largest_batch = std::max<int64_t>(largest_batch, (int64_t)members.size());
+                for (size_t i = 0; i < members.size(); i++) {
+                    Run* r = members[i];
+                    try {
+                        if (members.size() > 1) fprintf(r->log.f, "cloudd: evaluated together with %zu other request(s)\n", members.size() - 1);
+                        cloud_finish(r->the_io(), r->job, outs[i].data(), outs[i].size() / ((size_t)r->job.params.n + 1), dt);
+                        r->reply_ok(0);
+                    } catch (...) {
+                        r->fail(std::current_exception());
+                    }
+                }
+            } catch (...) {
+                for (Run* r : members)
+                    if (!r->failed && r->req->log.empty()) r->fail(std::current_exception());
+            }
+        }
+        runs.clear();
     }
 
     DaemonConfig cfg_;
@@ -285,37 +409,80 @@ int64_t daemon_serve(const DaemonConfig& cfg) {
     }
     int64_t served = 0;
     bool running = true;
+    // Requests that arrive within `batch_window_ms` of the first one of a round are answered together (see
+    // Server::handle_batch).  0 = one request at a time, like the reference.
+    const int window_ms = cfg.batch_window_ms;
+    const size_t max_batch = cfg.max_batch > 0 ? (size_t)cfg.max_batch : 1;
     while (running && !g_stop && (cfg.max_requests < 0 || served < cfg.max_requests)) {
-        Fd c(accept(lfd.fd, nullptr, nullptr));
-        if (c.fd < 0) {
+        std::vector<std::unique_ptr<Fd>> conns;
+        std::vector<Server::Pending> reqs;
+        auto take = [&](int fd) {  // reads one request; returns false when the client went away or sent garbage that was answered
+            std::unique_ptr<Fd> c(new Fd(fd));
+            ReqHeader h{};
+            if (!read_full(c->fd, &h, sizeof h)) return;
+            Server::Pending p;
+            p.op = h.op;
+            if (h.magic != kDaemonMagic || h.version != kDaemonVersion) {
+                p.op = 0;
+                p.rc = IEACHE_EINVAL;
+                p.log = "bad magic or protocol version";
+            } else if (h.payload_len > kDaemonMaxPayload) {
+                p.op = 0;
+                p.rc = IEACHE_EINVAL;
+                p.log = "payload too large";
+            } else {
+                try {
+                    p.payload.resize((size_t)h.payload_len);
+                } catch (const std::bad_alloc&) {
+                    return;
+                }
+                if (h.payload_len && !read_full(c->fd, p.payload.data(), p.payload.size())) return;
+            }
+            conns.push_back(std::move(c));
+            reqs.push_back(std::move(p));
+        };
+        const int first = accept(lfd.fd, nullptr, nullptr);
+        if (first < 0) {
             if (errno == EINTR && !g_stop) continue;
             break;
         }
-        ReqHeader h{};
-        std::string log;
-        std::vector<unsigned char> payload, data;
-        int32_t rc;
-        if (!read_full(c.fd, &h, sizeof h)) continue;  // client went away
-        if (h.magic != kDaemonMagic || h.version != kDaemonVersion) {
-            rc = IEACHE_EINVAL;
-            log = "bad magic or protocol version";
-        } else if (h.payload_len > kDaemonMaxPayload) {
-            rc = IEACHE_EINVAL;
-            log = "payload too large";
-        } else {
-            bool ok = true;
-            try {
-                payload.resize((size_t)h.payload_len);
-            } catch (const std::bad_alloc&) {
-                ok = false;
+        take(first);
+        if (window_ms > 0) {
+            struct timeval t0;
+            gettimeofday(&t0, nullptr);
+            while (reqs.size() < max_batch && (cfg.max_requests < 0 || served + (int64_t)reqs.size() < cfg.max_requests)) {
+                struct timeval now;
+                gettimeofday(&now, nullptr);
+                const long spent = (now.tv_sec - t0.tv_sec) * 1000L + (now.tv_usec - t0.tv_usec) / 1000L;
+                if (spent >= window_ms) break;
+                struct pollfd pfd{lfd.fd, POLLIN, 0};
+                const int pr = poll(&pfd, 1, (int)(window_ms - spent));
+                if (pr <= 0 || !(pfd.revents & POLLIN)) break;
+                const int fd = accept(lfd.fd, nullptr, nullptr);
+                if (fd < 0) break;
+                take(fd);
             }
-            if (!ok || (h.payload_len && !read_full(c.fd, payload.data(), payload.size()))) continue;
-            rc = server.handle(h.op, payload, &log, &data);
-            if (h.op == DAEMON_SHUTDOWN) running = false;
         }
-        RespHeader r{kDaemonMagic, rc, (uint64_t)log.size(), (uint64_t)data.size()};
-        if (write_full(c.fd, &r, sizeof r) && write_full(c.fd, log.data(), log.size())) (void)write_full(c.fd, data.data(), data.size());
-        served++;
+        // requests refused while reading (op 0) keep their canned answer; the rest goes through the server
+        std::vector<Server::Pending> work;
+        std::vector<size_t> where;
+        for (size_t i = 0; i < reqs.size(); i++)
+            if (reqs[i].op != 0) {
+                where.push_back(i);
+                work.push_back(std::move(reqs[i]));
+            }
+        server.handle_batch(work);
+        for (size_t j = 0; j < work.size(); j++) {
+            if (work[j].op == DAEMON_SHUTDOWN) running = false;
+            reqs[where[j]] = std::move(work[j]);
+        }
+        for (size_t i = 0; i < reqs.size(); i++) {
+            const Server::Pending& p = reqs[i];
+            RespHeader r{kDaemonMagic, p.rc, (uint64_t)p.log.size(), (uint64_t)p.data.size()};
+            if (write_full(conns[i]->fd, &r, sizeof r) && write_full(conns[i]->fd, p.log.data(), p.log.size()))
+                (void)write_full(conns[i]->fd, p.data.data(), p.data.size());
+            served++;
+        }
     }
     g_listen_fd = -1;
     sigaction(SIGINT, &old_int, nullptr);

@@ -2,7 +2,9 @@
 // keys on every `./cloud` launch (Cloud/cloud.c:656-663, once per operator of every expression).
 // Here one process keeps the cloud key on the GPU and serves the same contract over a local
 // (AF_UNIX) stream socket: either "run the files in this directory" or "here is cloud.data and
-// the operator, send answer.data back".  One request at a time, like the reference.
+// the operator, send answer.data back".  One request at a time, like the reference -- or, with a batching
+// window (DaemonConfig::batch_window_ms, IEACHE_DAEMON_BATCH_WINDOW_MS), the requests of several clients at once:
+// those asking for the same circuit are evaluated as one level-batched launch sequence, which is what fills a GPU.
 //
 // Wire format (little-endian, no padding):
 //   request : u32 magic 'IEAC' | u32 version (1) | u32 op | u32 flags (0) | u64 payload_len | payload
@@ -14,6 +16,7 @@
 //   op RUN_DATA : payload = i32 operator | cloud.data bytes; response data = answer.data bytes
 //                 (metadata key = the daemon's nbit key)
 //   op SHUTDOWN : no payload; the daemon answers and exits its loop
+//   op STATS    : no payload; log = "evaluations=E batched_requests=R largest_batch=B"
 //   rc: 0 or 126 as main() of cloud.c, negative IEACHE_E* on failure (message in log)
 #pragma once
 #include <cstddef>
@@ -25,7 +28,7 @@ namespace ieache {
 
 constexpr uint32_t kDaemonMagic = 0x43414549u;  // "IEAC"
 constexpr uint32_t kDaemonVersion = 1;
-enum DaemonOp : uint32_t { DAEMON_PING = 1, DAEMON_RUN_DIR = 2, DAEMON_RUN_DATA = 3, DAEMON_SHUTDOWN = 4 };
+enum DaemonOp : uint32_t { DAEMON_PING = 1, DAEMON_RUN_DIR = 2, DAEMON_RUN_DATA = 3, DAEMON_SHUTDOWN = 4, DAEMON_STATS = 5 };
 constexpr uint64_t kDaemonMaxPayload = 64ull << 20;  // cloud.data is 1.8 MB at n=630
 
 struct DaemonConfig {
@@ -35,6 +38,10 @@ struct DaemonConfig {
     int device = 0;
     int64_t max_requests = -1;   // < 0: until SHUTDOWN
     bool announce = true;        // print "cloudd: ready on <path>" once listening
+    // Requests arriving within this many milliseconds of the first one of a round are answered together, those that
+    // ask for the same circuit as ONE level-batched evaluation.  0 = one request at a time.
+    int batch_window_ms = 0;
+    int max_batch = 256;
 };
 
 // Blocks serving requests; returns the number served.  Throws on setup failure

@@ -15,7 +15,7 @@ import time
 
 MAGIC = 0x43414549  # "IEAC"
 VERSION = 1
-OP_PING, OP_RUN_DIR, OP_RUN_DATA, OP_SHUTDOWN = 1, 2, 3, 4
+OP_PING, OP_RUN_DIR, OP_RUN_DATA, OP_SHUTDOWN, OP_STATS = 1, 2, 3, 4, 5
 MAX_PAYLOAD = 64 << 20
 _REQ = struct.Struct("<IIIIQ")
 _RESP = struct.Struct("<IiQQ")
@@ -83,18 +83,32 @@ def run_data(socket_path, operator_code, cloud_data):
     return request(socket_path, OP_RUN_DATA, struct.pack("<i", int(operator_code)) + bytes(cloud_data))
 
 
+def stats(socket_path):
+    """-> dict(evaluations, batched_requests, largest_batch): how the daemon has grouped its RUN_* requests so far."""
+    rc, log, _ = request(socket_path, OP_STATS, timeout=30.0)
+    if rc != 0:
+        raise DaemonError("stats: %s" % log)
+    return {k: int(v) for k, v in (kv.split("=") for kv in log.split())}
+
+
 def shutdown(socket_path):
     return request(socket_path, OP_SHUTDOWN, timeout=30.0)[0]
 
 
-def spawn(socket_path, cloud_key, nbit_key=None, device=0, wait=120.0, env=None):
-    """Start `cloudd` and wait until it answers a ping (the key load + transform take ~0.4 s at n=630)."""
+def spawn(socket_path, cloud_key, nbit_key=None, device=0, wait=120.0, env=None, batch_window_ms=0, max_batch=None):
+    """Start `cloudd` and wait until it answers a ping (the key load + transform take ~0.4 s at n=630).
+    batch_window_ms > 0: requests arriving within that window are answered together, same-circuit ones as one
+    level-batched GPU run (csrc/daemon.h)."""
     exe = os.path.join(_PKG, "cloudd")
     if not os.path.exists(exe):
         raise DaemonError("%s is missing: run __graft_entry__.build()" % exe)
     cmd = [exe, "--socket", os.fspath(socket_path), "--key", os.fspath(cloud_key), "--device", str(device)]
     if nbit_key:
         cmd += ["--nbit", os.fspath(nbit_key)]
+    if batch_window_ms:
+        cmd += ["--batch-window-ms", str(int(batch_window_ms))]
+    if max_batch:
+        cmd += ["--max-batch", str(int(max_batch))]
     proc = subprocess.Popen(cmd, env=env)
     t0 = time.monotonic()
     while time.monotonic() - t0 < wait:

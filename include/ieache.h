@@ -264,6 +264,10 @@ int ieache_verif(const char* secret_key_path, const char* nbit_key_path, const c
  *    csrc/daemon.h); the `cloud` shim forwards to it when              *
  *    IEACHE_DAEMON=<socket path> is set.                               *
  * ------------------------------------------------------------------ */
+/* IEACHE_DAEMON_BATCH_WINDOW_MS=T (cloudd --batch-window-ms T; default 0 = one request at a time like the
+ * reference): requests arriving within T ms are answered together, and those asking for the same circuit are
+ * evaluated as ONE level-batched run -- a lone expression keeps a few of the GPU's 1 024 workgroup slots busy,
+ * a hundred concurrent ones fill it.  IEACHE_DAEMON_MAX_BATCH caps a round (default 256). */
 /* Blocks.  nbit_key_path may be NULL (= nbit.key next to cloud.key; only
  * RUN_DATA needs it).  max_requests < 0: until a shutdown request or
  * SIGINT/SIGTERM.  Returns the number of requests served or IEACHE_E*. */

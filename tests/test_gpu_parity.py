@@ -4,6 +4,7 @@ P2 (bit-exact): every LWE coefficient the GPU produces equals the exact-integer
 oracle's.  P1: outputs decrypt to integer arithmetic.  """
 import json
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -907,6 +908,86 @@ def test_resident_key_daemon(ia, O, tmp_path):
         assert rc == 0 and ok and tools.verif_interpret(1, *tools.verif(other)) == 42
         assert daemon.shutdown(sock) == 0
         assert proc.wait(timeout=60) == 0 and not sock.exists()
+    finally:
+        if proc.poll() is None:
+            proc.send_signal(signal.SIGTERM)
+            try:
+                proc.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+
+
+def test_daemon_batches_concurrent_requests(ia, O, tmp_path):
+    """cloudd --batch-window-ms: requests of several clients that arrive together are answered together, those asking
+    for the same circuit as ONE level-batched evaluation.  Every client still gets exactly its own answer: the value
+    samples equal a one-at-a-time run (and the oracle) bit for bit."""
+    import signal
+    import threading
+    from ieache_amd import daemon, tools
+    p = ia.default_params().copy(n=6, N=64)
+    S = 4 * p.n + 16
+    tools.keygen_files(tmp_path, p)
+    _, bk, ksk = tools.read_cloud_key(tmp_path / "cloud.key")
+    ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, bk, ksk)
+    # eight clients: six 32-bit additions (one circuit), one subtraction, one 64-bit multiplication
+    jobs = []
+    for i in range(8):
+        d = tmp_path / ("client%d" % i)
+        d.mkdir()
+        for f in ("cloud.key", "nbit.key", "secret.key"):
+            os.link(tmp_path / f, d / f)
+        operator, bits, a, b = (1, 32, 1000 + i, 77 * i) if i < 6 else ((2, 32, 5000, 123) if i == 6 else (3, 64, (1 << 40) + 9, (1 << 33) + 5))
+        tools.alice(d, 0, bits, a, seed=100 + i)
+        tools.alice(d, 0, bits, b, seed=200 + i, append=True)
+        jobs.append((d, operator, bits, a, b))
+    sock = tmp_path / "cloudd.sock"
+    proc = daemon.spawn(sock, tmp_path / "cloud.key", batch_window_ms=400, max_batch=64)
+    try:
+        results = [None] * 8
+        barrier = threading.Barrier(8)
+
+        def client(i):
+            d, operator, bits, a, b = jobs[i]
+            barrier.wait()
+            if i % 2:  # RUN_DATA: bytes over the socket
+                rc, log, ans = daemon.run_data(sock, {1: 1, 2: 2, 3: 4}[operator], (d / "cloud.data").read_bytes())
+                (d / "answer.data").write_bytes(ans)
+                results[i] = (rc, log)
+            else:      # RUN_DIR: what the `cloud` shim sends
+                (d / "operator.txt").write_text({1: "1", 2: "2", 3: "4"}[operator])
+                results[i] = daemon.run_dir(sock, d)
+
+        threads = [threading.Thread(target=client, args=(i,)) for i in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        st = daemon.stats(sock)
+        assert st["batched_requests"] == 8 and st["largest_batch"] >= 2 and st["evaluations"] < 8, st
+        together = 0
+        for i, (d, operator, bits, a, b) in enumerate(jobs):
+            rc, log = results[i]
+            assert rc == 0 and "Computation Time" in log, (i, log)
+            together += "evaluated together" in log
+            assert (d / "answer.data").stat().st_size == 352 * S
+            code, bit_size, words = tools.verif(d)
+            exp = {1: a + b, 2: a - b, 3: a * b}[operator]
+            assert tools.verif_interpret({1: 1, 2: 2, 3: 4}[operator], code, bit_size, words) == exp, i
+            data = tools.read_samples(d / "cloud.data", p.n).reshape(22, 32, p.n + 1)
+            rc2, ref = ck.cloud_values({1: 1, 2: 2, 3: 4}[operator], 0, bits, data[2:10], data[13:21], data[10])
+            ans = tools.read_samples(d / "answer.data", p.n).reshape(11, 32, p.n + 1)
+            assert rc2 == 0 and np.array_equal(ans[2:], ref), i
+        assert together >= 2
+        # failures inside a round are answered individually and do not take the round down
+        bad = threading.Thread(target=lambda: results.__setitem__(0, daemon.run_data(sock, 1, b"short")))
+        good = threading.Thread(target=lambda: results.__setitem__(1, daemon.run_data(sock, 1, (jobs[1][0] / "cloud.data").read_bytes())))
+        bad.start()
+        good.start()
+        bad.join(timeout=120)
+        good.join(timeout=120)
+        assert results[0][0] == -5 and results[1][0] == 0 and len(results[1][2]) == 352 * S
+        assert daemon.shutdown(sock) == 0
+        assert proc.wait(timeout=60) == 0
     finally:
         if proc.poll() is None:
             proc.send_signal(signal.SIGTERM)
