@@ -25,7 +25,9 @@ int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const d
 // the kernels' twiddle table (twiddle_table_elems() double2 in device memory), built once per context
 size_t twiddle_table_elems();
 void build_twiddle_table(double2* d_tw, hipStream_t stream);
-// kernel variant: 0 = LDS transposes, wave-local sync (default; IEACHE_BR_VARIANT overrides); 1 = same with
+// kernel variant: 0 = default (IEACHE_BR_VARIANT overrides): wave-local sync, the forward transforms' lane-high transpose
+// cross-lane (v_permlane*_swap / DPP), every other transpose -- and the paired inverse -- through LDS (+0.8 % over all-LDS,
+// which is variant 12); 1 = all-LDS with
 // s_memtime diagnostics printed to stderr; 2 = LDS transposes with workgroup barriers; 3 = cross-lane
 // (DPP / v_permlane*_swap) transposes; 4 = 3 with diagnostics; 5 / 6 = only the lane-high / lane-low transpose cross-lane;
 // 10 = forward-transform LDS stores interleaved with the twiddle multiplies that feed them (measured: no gain);

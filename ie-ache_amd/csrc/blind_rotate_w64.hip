@@ -483,7 +483,7 @@ __global__ __launch_bounds__(128) void k_br_prologue(DevKeys K, WorkDesc W, uint
 // limbs) and inverse-transforms them.  Each forward spectrum is handed to the
 // partner wave through the producing wave's own (then idle) transpose tile.
 // dynamic LDS: sT [2][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32
-template <int L, int BGBIT, bool DIAG, bool WSYNC, int XLANE = 0, int ILV = 0, bool ENDBAR = false>
+template <int L, int BGBIT, bool DIAG, bool WSYNC, int XLANE = 0, int ILV = 0, bool ENDBAR = false, bool PAIRINV = false>
 __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const double2* __restrict__ bkf,
                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
                                                            int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 #pragma unroll 1
         for (int q = 1; q < L; q++) digit_row(q, std::false_type{});
         // back to coefficients, round, recombine the two limbs, accumulate into polynomial `wave`
-        if (XLANE == 0) {
+        if (XLANE == 0 || PAIRINV) {  // PAIRINV: cross-lane transposes in the forward transforms only
             fft512_inverse_pair<WSYNC>(s[0], s[1], sT, lane, R);
         } else {
             fft512_inverse<WSYNC, XLANE>(s[0], sT, lane, R);
@@ -934,9 +934,11 @@ static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream
         case 4: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw); break;
         case 5: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
         case 11: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 0, 0, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
+        case 12: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;  // every transpose through LDS (round 1's default)
         case 10: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 0, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
         case 6: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 2>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
-        default: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
+        // default since round 2: the forward transforms' first (lane-high) transpose cross-lane, everything else through LDS
+        default: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 1, 0, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
     }
 }
 

@@ -621,7 +621,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         ctx.set_option("br_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref), sl
     ctx.set_option("br_slice", 16)
-    for variant in (2, 3, 5, 6, 10, 11):                   # workgroup-barrier sync; cross-lane (DPP/permlane) transposes: both /
+    for variant in (2, 3, 5, 6, 10, 11, 12):                   # workgroup-barrier sync; cross-lane (DPP/permlane) transposes: both /
         ctx.set_option("br_variant", variant)              # lane-high only / lane-low only; stores interleaved with multiplies
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:300], b[:300]), ref[:300]), variant
     ctx.set_option("br_variant", 7)                        # 2L-waves-per-gate (latency) kernel, forced for every launch size
@@ -660,7 +660,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
     ctx.force_generic(False)
     with pytest.raises(ia.IeacheError):
-        ctx.set_option("br_variant", 12)
+        ctx.set_option("br_variant", 13)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("br_slice", 4097)
     with pytest.raises(ia.IeacheError):
