@@ -31,6 +31,9 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6          # 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 LANES, FLOP_PER_INST = 64, 2          # one wave-instruction = 64 lanes; priced as an FMA (2 flop) like the peak
+# FP64 instructions among them, per gate and CMux step (2 waves x 1 684: 5 transforms x 216, 12 row products x 32, twists
+# 224 -- counted in the kernel's ISA): the part of the vector issue that is the algorithm itself
+FP64_INSTS_PER_GATE_STEP = 3368
 
 WORKLOADS = {
     # name: (circuit kind, bits, default per-GPU batch, BASELINE.json config)
@@ -97,7 +100,9 @@ def roofline(p, stats, gate_rate, pmc):
                     "achieved": br_gate_rate * flop_per_gate * 1e-12, "peak": FP64_VALU_PEAK_TFLOPS,
                     "frac": br_gate_rate * flop_per_gate * 1e-12 / FP64_VALU_PEAK_TFLOPS,
                     "valu_insts_per_gate": insts * p.n, "valu_insts_source": pmc.get("source"),
-                    "note": "achieved = blind-rotation gates/s (HIP events over its launches) x SQ_INSTS_VALU per gate x 64 lanes x 2 flop; "
+                    "frac_fp64_only": br_gate_rate * FP64_INSTS_PER_GATE_STEP * p.n * LANES * FLOP_PER_INST * 1e-12 / FP64_VALU_PEAK_TFLOPS,
+                    "note": "achieved = blind-rotation gates/s (HIP events over its launches) x SQ_INSTS_VALU per gate x 64 lanes x 2 flop "
+                            "= vector-issue utilisation (index arithmetic and cross-lane moves included; frac_fp64_only counts the FP64 instructions alone); "
                             "100 %% = %.0f gates/s per GPU at 2.4 GHz" % (FP64_VALU_PEAK_TFLOPS * 1e12 / flop_per_gate)})
         cyc = pmc.get("shader_cycles_per_gate_step")
         if cyc and br_avg_ms > 0:
