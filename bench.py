@@ -31,9 +31,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6          # 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 LANES, FLOP_PER_INST = 64, 2          # one wave-instruction = 64 lanes; priced as an FMA (2 flop) like the peak
-# FP64 instructions among them, per gate and CMux step (2 waves x 1 684: 5 transforms x 216, 12 row products x 32, twists
-# 224 -- counted in the kernel's ISA): the part of the vector issue that is the algorithm itself
-FP64_INSTS_PER_GATE_STEP = 3368
+# (the FP64 instructions among them -- the part of the vector issue that is the algorithm itself -- are counted in the
+# kernel's ISA and recorded next to the counters in profiles/traffic.json: fp64_insts_per_gate_step)
 
 WORKLOADS = {
     # name: (circuit kind, bits, default per-GPU batch, BASELINE.json config)
@@ -62,7 +61,8 @@ def pmc_counters(kernel_variant):
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(kernel_variant)
         if not tj:
             return None
-        out = {"hbm_bytes_per_gate_step": tj["hbm_bytes_per_gate_step"], "l2_hit_rate": tj.get("l2_hit_rate"),
+        out = {"kernel": tj.get("kernel"), "fp64_insts_per_gate_step": tj.get("fp64_insts_per_gate_step", 0),
+               "hbm_bytes_per_gate_step": tj["hbm_bytes_per_gate_step"], "l2_hit_rate": tj.get("l2_hit_rate"),
                "source": tj.get("pmc_summary", tj.get("source")), "shader_cycles_per_gate_step": tj.get("shader_cycles_per_gate_step")}
         summ = tj.get("pmc_summary")
         if summ:
@@ -90,7 +90,7 @@ def roofline(p, stats, gate_rate, pmc):
     ks_gate_rate = stats.bootstraps / max(1e-9, stats.keyswitch_ms * 1e-3)
     insts = pmc.get("valu_insts_per_gate_step") if pmc else None
     traffic = pmc["hbm_bytes_per_gate_step"] * gates_per_launch * steps_per_launch if pmc else None
-    out = {"kernel": "k_blind_rotate_w2", "avg_launch_ms": br_avg_ms, "gates_per_launch": gates_per_launch,
+    out = {"kernel": (pmc or {}).get("kernel", "k_blind_rotate"), "avg_launch_ms": br_avg_ms, "gates_per_launch": gates_per_launch,
            "cmux_steps_per_launch": steps_per_launch, "traffic": traffic,
            "blind_rotate_share": stats.blind_rotate_ms / max(1e-9, stats.total_ms),
            "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms)}
@@ -100,7 +100,7 @@ def roofline(p, stats, gate_rate, pmc):
                     "achieved": br_gate_rate * flop_per_gate * 1e-12, "peak": FP64_VALU_PEAK_TFLOPS,
                     "frac": br_gate_rate * flop_per_gate * 1e-12 / FP64_VALU_PEAK_TFLOPS,
                     "valu_insts_per_gate": insts * p.n, "valu_insts_source": pmc.get("source"),
-                    "frac_fp64_only": br_gate_rate * FP64_INSTS_PER_GATE_STEP * p.n * LANES * FLOP_PER_INST * 1e-12 / FP64_VALU_PEAK_TFLOPS,
+                    "frac_fp64_only": br_gate_rate * pmc.get("fp64_insts_per_gate_step", 0) * p.n * LANES * FLOP_PER_INST * 1e-12 / FP64_VALU_PEAK_TFLOPS,
                     "note": "achieved = blind-rotation gates/s (HIP events over its launches) x SQ_INSTS_VALU per gate x 64 lanes x 2 flop "
                             "= vector-issue utilisation (index arithmetic and cross-lane moves included; frac_fp64_only counts the FP64 instructions alone); "
                             "100 %% = %.0f gates/s per GPU at 2.4 GHz" % (FP64_VALU_PEAK_TFLOPS * 1e12 / flop_per_gate)})
@@ -406,13 +406,17 @@ def main():
             "config": {"workload": config_name, "circuit": "%s%d" % (args.workload.rstrip("0123456789"), bits),
                        "batch_per_gpu": batch, "bootstraps_per_expr": int(info.bootstraps), "levels": int(info.depth),
                        "params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2",
-                       "arithmetic": "Torus32 = int32 with wraparound; the negacyclic products inside the external product run as an exact two-limb f64 transform",
+                       "arithmetic": "Torus32 = int32 with wraparound; the negacyclic products inside the external product run as one f64 transform "
+                                     "of the 32-bit coefficients with a rounding guard (bit-identical to the two-limb exact transform, which "
+                                     "exact_fft=1 selects; fft_guard below)",
                        "parallelism": "batch-sharded x%d" % world, "kernel": ctx.kernel_variant,
                        "key_broadcast_s": round(t_bcast, 4),
                        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
                        "collective_backend": args.backend if world > 1 else None,
                        "per_rank_gate_ops_per_s": [info.bootstraps * batch * args.steps / t for t in per_rank]},
             "roofline": roofline(p, stats, value / world, pmc),
+            "fft_guard": dict(zip(("max_rounding_deviation", "reruns_on_two_limb_kernel"), ctx.fft_guard()),
+                              limit=1.0 / 16, wrong_bit_at=0.5),
         }
         if mul_leg:
             out["mul32"] = mul_leg

@@ -19,9 +19,16 @@ size_t state_bytes_per_item(const Params& p);
 // (`slice`, 1..64; 0 = default 16 or IEACHE_BR_SLICE).  state: items * state_bytes_per_item() bytes of scratch.
 // ext rows of N+4 int32 (may be null), dbg_acc [items][2][N] (may be null; when set, pass ext = null).
 // Returns the number of k_blind_rotate_w2 launches issued.
-int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const dev::WorkDesc& W, int64_t items,
-           void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
-           const double2* d_twiddles, hipStream_t stream);
+// d_bkf1 / guard: the one-limb spectrum and the two-word guard record of k_blind_rotate_w1 (may be null for the
+// two-limb variants).
+int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard,
+           const dev::WorkDesc& W, int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice,
+           int32_t variant, const double2* d_twiddles, hipStream_t stream);
+// one-limb form (k_blind_rotate_w1): raw BK -> spectrum [n][2l][2][8][64] double2
+size_t spectrum1_elems(const Params& p);
+void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1, hipStream_t stream);
+size_t lds_bytes_w1();
+int gates_per_workgroup_w1();
 // the kernels' twiddle table (twiddle_table_elems() double2 in device memory), built once per context
 size_t twiddle_table_elems();
 void build_twiddle_table(double2* d_tw, hipStream_t stream);
@@ -37,6 +44,10 @@ int32_t default_variant();
 // 7 = 2L waves per gate (k_blind_rotate_wide): lower latency per gate, for launches of few gates;
 // takes any slice length up to n (one launch for the whole rotation)
 constexpr int32_t kVariantWide = 7;
+// 13 = one wave per gate on the one-limb spectrum with the rounding guard (k_blind_rotate_w1; the evaluator's default for
+// wide launches), 14 = the same without the guard arithmetic (measurement only).  Bit-identical to the two-limb kernels
+// as long as the guard stays silent.
+constexpr int32_t kVariantOneLimb = 13;
 
 }  // namespace w64
 }  // namespace ieache

@@ -441,6 +441,29 @@ __global__ __launch_bounds__(64) void k_bk_to_spectrum_w64(const Torus32* bk_raw
     }
 }
 
+// ---- key preparation, one-limb form: BK polynomial -> spectrum of its 32-bit coefficients ----
+// bkf1 layout: [n][2L rows][c = 2][k2 = 8][lane = 64]   (half the two-limb form: 61.9 MB at n = 630)
+__global__ __launch_bounds__(64) void k_bk_to_spectrum_w64_1(const Torus32* bk_raw, double2* bkf1) {
+    __shared__ __align__(16) double2 sT[kTile];
+    __shared__ __align__(16) double2 sTw[kTwElems];
+    const int lane = threadIdx.x;
+    build_twiddles(sTw, lane, 64);
+    __syncthreads();
+    const LaneRoots R = make_roots(sTw, lane);
+    const size_t poly = blockIdx.x;  // (i * 2L + row) * 2 + c
+    const Torus32* src = bk_raw + poly * kN;
+    double2 x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double2 v = make_double2((double)src[64 * r + lane], (double)src[64 * r + lane + kM]);
+        x[r] = r == 0 ? v : cmulx<false>(v, twist_reg(r));
+    }
+    fft512_forward<true>(x, sT, lane, R);
+    double2* dst = bkf1 + (poly * 8) * 64 + lane;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) dst[k2 * 64] = x[k2];
+}
+
 // ---- K0..K2: gate pre-combination, mod-switch, test-vector init ----
 // One 128-thread workgroup per gate instance.  Writes the rotation amounts
 // bara[n] (u16, row stride nb) and the initial accumulator [2][1024] to the
@@ -655,6 +678,162 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 }
 
 
+// ---- K3 (+K4), throughput form: ONE wave per gate instance, one-limb spectrum ----
+// The two-limb transform above is exact by construction (every rounded sum stays below 2^37 of the 2^53 an FP64
+// mantissa holds) and pays for it with a second inverse transform and a second set of row products per output
+// polynomial.  libtfhe itself multiplies with ONE double-precision transform of the 32-bit coefficients; the sums
+// then reach 2^49.6 in the worst case and ~2^43 on real data, where the transform's rounding error is ~2^-9 of an
+// integer step (measured max 0.007) -- far from the 0.5 that would change a rounded
+// coefficient, but not provably so.  This kernel takes that form and WATCHES the error: every inverse-transformed
+// coefficient's distance to the nearest integer is folded into a running maximum, published per launch (guard[1],
+// float bits) and counted (guard[0]) when it exceeds kGuardLimit; the evaluator then repeats the call on the
+// two-limb kernel.  With 6 forward + 2 inverse transforms and 12 row products per step (10 + 24 before) the whole
+// step fits ONE wave: no spectra cross waves, so the step has no workgroup barrier at all, and a SIMD's two
+// resident waves belong to unrelated gates that never wait for each other.
+// Four gates share a workgroup only for the twiddle table.
+// dynamic LDS: sT [4][kTile] double2 | tw [kTwElems] double2 | acc [4][2][1024] int32     (78 848 B -> 2 per CU)
+constexpr int kW1Gates = 4;
+constexpr float kGuardLimit = 0.0625f;
+template <int L, int BGBIT, bool GUARD, int XLANE = 1, bool EARLYB = false>
+__global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K, const double2* __restrict__ bkf1,
+                                                                      const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                                      int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
+                                                                      Torus32* ext, unsigned* guard,
+                                                                      const double2* __restrict__ gtw) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* sT_all = reinterpret_cast<double2*>(smem);
+    double2* sTw = sT_all + kW1Gates * kTile;
+    int32_t* acc_all = reinterpret_cast<int32_t*>(sTw + kTwElems);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;
+    int32_t* acc = acc_all + wave * 2 * kN;
+    const int64_t item = (int64_t)blockIdx.x * kW1Gates + wave;
+    load_twiddles(sTw, gtw, tid, 64 * kW1Gates);
+    __syncthreads();  // the only workgroup barrier: from here on a wave touches nothing another wave writes
+    if (item >= items) return;
+    const LaneRoots R = make_roots(sTw, lane);
+    const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[64 * r + lane] = src[64 * r + lane];
+    }
+    wave_sync();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+    double dev_max = 0.0;
+
+    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
+        if (a == 0) continue;  // wave-uniform; exact arithmetic makes the step a no-op
+        // BK_i rows [2L][2][8][64]
+        const double2* __restrict__ bki = bkf1 + (size_t)i * (2 * L * 2 * kM) + lane;
+        double2 s[2][8];
+        uint32_t v0[8], v1[8];
+        auto decompose = [&](const int32_t* accp) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int32_t j = 64 * r + lane;
+                v0[r] = (((uint32_t)rot_coef(accp, j, a, kN) - (uint32_t)accp[j]) + dec_offset) ^ dec_offset;
+                v1[r] = (((uint32_t)rot_coef(accp, j + kM, a, kN) - (uint32_t)accp[j + kM]) + dec_offset) ^ dec_offset;
+            }
+        };
+        auto digit_row = [&](const int sh, const double2* __restrict__ brow, auto first) {
+            constexpr bool FIRST = decltype(first)::value;  // the first row's products initialise s
+            double2 x[8], bA[8], bB[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) bA[k] = brow[k * 64];         // -> output polynomial 0
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
+                const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
+                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            }
+            if (EARLYB) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) bB[k] = brow[(8 + k) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft512_forward<true, XLANE, 0>(x, sT, lane, R);
+            if (!EARLYB) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) bB[k] = brow[(8 + k) * 64];   // -> output polynomial 1
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[0][k] = FIRST ? cmulx<false>(x[k], bA[k])
+                                : make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[0][k].x)),
+                                               fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[0][k].y)));
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[1][k] = FIRST ? cmulx<false>(x[k], bB[k])
+                                : make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
+                                               fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
+        };
+        decompose(acc);
+        digit_row(32 - BGBIT, bki, std::true_type{});
+#pragma unroll 1
+        for (int row = 1; row < 2 * L; row++) {
+            if (row == L) decompose(acc + kN);
+            const int q = row >= L ? row - L : row;
+            digit_row(32 - (q + 1) * BGBIT, bki + (size_t)row * (2 * kM), std::false_type{});
+        }
+        fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
+        // back to coefficients: s[c] holds output polynomial c; round and accumulate
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            uint32_t* accc = reinterpret_cast<uint32_t*>(acc) + c * kN;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const double2 z = r == 0 ? make_double2(s[c][0].x * (1.0 / 512.0), s[c][0].y * (1.0 / 512.0))
+                                         : cmulx<true>(s[c][r], untwist_reg(r));
+                const double t0 = z.x + kMagic, t1 = z.y + kMagic;
+                if (GUARD) {
+                    dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
+                    dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
+                }
+                const int32_t j = 64 * r + lane;
+                // ds_add_u32 (no return): one LDS instruction instead of read, add, write
+                __hip_atomic_fetch_add(&accc[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&accc[j + kM], (uint32_t)__double2loint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        wave_sync();
+    }
+    if (GUARD) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);  // non-negative floats order like their bit patterns
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
+        }
+    }
+    if (ext) {
+        // K4: sample extract after the last slice
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = lane; j <= kN; j += 64)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[64 * r + lane] = src[64 * r + lane];
+    }
+}
+
 // ---- K3 (+K4), latency-oriented: 2L waves per gate instance ----
 // For narrow levels (a single expression, the reference's own mode) the time of a level is the
 // LATENCY of one blind rotation, and two waves walking 3 forward + 2 inverse transforms one after
@@ -850,6 +1029,9 @@ bool supported(const Params& p) {
 }
 
 size_t spectrum_elems(const Params& p) { return (size_t)p.n * p.kpl() * 4 * kM; }
+size_t spectrum1_elems(const Params& p) { return (size_t)p.n * p.kpl() * 2 * kM; }
+size_t lds_bytes_w1() { return (size_t)(kW1Gates * kTile + kTwElems) * sizeof(double2) + (size_t)kW1Gates * 2 * kN * 4; }
+int gates_per_workgroup_w1() { return kW1Gates; }
 
 size_t lds_bytes(const Params& p) {
     (void)p;
@@ -873,6 +1055,11 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream) {
 void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, hipStream_t stream) {
     const size_t npoly = (size_t)p.n * p.kpl() * 2;
     hipLaunchKernelGGL(k_bk_to_spectrum_w64, dim3((unsigned)npoly), dim3(64), 0, stream, d_bk_raw, d_bkf);
+}
+
+void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1, hipStream_t stream) {
+    const size_t npoly = (size_t)p.n * p.kpl() * 2;
+    hipLaunchKernelGGL(k_bk_to_spectrum_w64_1, dim3((unsigned)npoly), dim3(64), 0, stream, d_bk_raw, d_bkf1);
 }
 
 // diagnostic build (IEACHE_BR_VARIANT=1): per-segment s_memtime sums, printed per launch() call
@@ -942,6 +1129,29 @@ static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream
     }
 }
 
+template <int L, int BGBIT>
+static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const DevKeys& K, const double2* d_bkf1,
+                            const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e,
+                            unsigned* guard, const double2* gtw) {
+    const dim3 grid((unsigned)((items + kW1Gates - 1) / kW1Gates)), blk(64 * kW1Gates);
+#define IEACHE_W1(...)                                                                                                          \
+    {                                                                                                                           \
+        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_w1<L, BGBIT, __VA_ARGS__>,                 \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_w1()) == hipSuccess; \
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_w1"); \
+        hipLaunchKernelGGL((k_blind_rotate_w1<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
+                           st_acc, items, i0, i1, e, guard, gtw);                                                               \
+    }
+    switch (sub) {  // > 64 KiB of dynamic LDS has to be allowed explicitly, per instantiation
+        case 1: IEACHE_W1(false) break;          // no guard arithmetic (measurement)
+        case 2: IEACHE_W1(true, 0) break;        // forward transposes through LDS
+        case 3: IEACHE_W1(true, 3) break;        // both forward transposes cross-lane
+        case 4: IEACHE_W1(true, 1, true) break;  // both BK blocks of a row requested before its transform
+        default: IEACHE_W1(true) break;
+    }
+#undef IEACHE_W1
+}
+
 int32_t default_variant() {
     static const int32_t v = getenv("IEACHE_BR_VARIANT") ? atoi(getenv("IEACHE_BR_VARIANT")) : 0;
     return v;
@@ -952,9 +1162,11 @@ int32_t default_slice() {
     return s > 0 ? (s < 64 ? s : 64) : 16;  // <= 64: one rotation amount per lane
 }
 
-int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDesc& W, int64_t items, void* state,
-           Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant, const double2* d_twiddles,
-           hipStream_t stream) {
+int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
+           int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
+           const double2* d_twiddles, hipStream_t stream) {
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 4;
+    if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
     // IEACHE_BR_LDS_PAD=<bytes>: measurement aid -- extra dynamic LDS per workgroup lowers the number of
@@ -974,7 +1186,12 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
         Torus32* e = (i1 == nsteps) ? ext : nullptr;  // the last slice extracts instead of storing the accumulator
         launches++;
-        if (p.l == 3)
+        if (one_limb) {
+            if (p.l == 3)
+                launch_slice_w1<3, 7>(variant - kVariantOneLimb, items, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles);
+            else
+                launch_slice_w1<2, 10>(variant - kVariantOneLimb, items, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles);
+        } else if (p.l == 3)
             launch_slice<3, 7>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, d_twiddles);
         else
             launch_slice<2, 10>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, d_twiddles);
@@ -983,9 +1200,9 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const WorkDe
     if (nsteps == 0 && ext) {
         // degenerate (steps == 0): extraction straight from the initial accumulator
         if (p.l == 3)
-            launch_slice<3, 7>(0, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext, d_twiddles);
+            launch_slice<3, 7>(12, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext, d_twiddles);
         else
-            launch_slice<2, 10>(0, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext, d_twiddles);
+            launch_slice<2, 10>(12, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, 0, 0, ext, d_twiddles);
     }
     if (dbg_acc)
         (void)hipMemcpyAsync(dbg_acc, st_acc, (size_t)items * 2 * kN * 4, hipMemcpyDeviceToDevice, stream);

@@ -262,6 +262,13 @@ int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value) {
     return 0;
 }
 
+int ieache_ctx_fft_guard(const ieache_ctx* ctx, double* max_deviation, int64_t* reruns) {
+    if (!ctx) return fail(IEACHE_EINVAL, "null context");
+    if (max_deviation) *max_deviation = ctx->eval->fft_guard_max();
+    if (reruns) *reruns = ctx->eval->fft_guard_reruns();
+    return 0;
+}
+
 const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx) {
     if (!ctx) return "";
     const_cast<ieache_ctx*>(ctx)->variant = ctx->eval->kernel_variant();

@@ -81,14 +81,27 @@ public:
     // "ks_batch_min" (same threshold for the compiler-scheduled gate-batched kernel, the cross-check),
     // "br_slice" (CMux steps per blind-rotation launch, 1..64),
     // "br_wide_max" (launches of at most this many gate instances use the latency-oriented
-    // 2L-waves-per-gate kernel; default = the device's CU count, 0 = never), "br_variant".
+    // 2L-waves-per-gate kernel; default = the device's CU count, 0 = never), "br_variant",
+    // "exact_fft" (1 = two-limb blind rotation always), "one_limb_min" (launches of at least this many gate
+    // instances use the one-limb kernel; default 2 per CU + 1).
     // Returns false for an unknown name or a value out of range.
     bool set_option(const std::string& name, int64_t value);
     std::string kernel_variant() const;
+    // The one-limb blind rotation (k_blind_rotate_w1) rounds sums an FP64 transform carries with ~2^-9 of error instead of
+    // provably none; it records how far from an integer its coefficients came.  fft_guard_max(): the largest such distance
+    // over the context's life (0.5 would be a wrong bit; the kernel's limit is 1/16); fft_guard_reruns(): calls that crossed
+    // the limit and were therefore repeated on the two-limb kernel.  Option "exact_fft" = 1 uses the two-limb kernel always.
+    double fft_guard_max() const;
+    int64_t fft_guard_reruns() const;
+    bool fft_guard_tripped();  // internal: reads and re-arms the device-side record
 
     struct Impl;  // device buffers; defined in evaluator.hip
 
 private:
+    void gates_device_once(int32_t type, size_t count, const Torus32* d_a, const Torus32* d_b, Torus32* d_out, EvalStats* stats);
+    void mux_device_once(size_t count, const Torus32* d_a, const Torus32* d_b, const Torus32* d_c, Torus32* d_out, EvalStats* stats);
+    void eval_circuit_device_once(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out, EvalStats* stats);
+    void debug_blind_rotate_once(size_t count, const Torus32* d_x, Torus32* d_acc, int32_t steps);
     void init();
     void destroy();
     Params p_;

@@ -17,6 +17,8 @@
 // definition (and the CPU oracle) bit for bit, whatever the FFT schedule.
 #include "evaluator.h"
 
+#include <cstring>
+
 #include "blind_rotate_w64.h"
 #include "keyswitch_sliced.h"
 #include "device_common.h"
@@ -487,6 +489,14 @@ struct Evaluator::Impl {
     double2* bkf = nullptr;
     double2* bkf_w64 = nullptr;  // spectrum in the wave-per-gate kernel's layout
     double2* tw_w64 = nullptr;   // its twiddle table
+    double2* bkf1_w64 = nullptr; // one-limb spectrum of k_blind_rotate_w1
+    unsigned* fft_guard = nullptr;  // [0] launches whose rounding deviation exceeded the limit, [1] max deviation (float bits)
+    bool exact_fft = false;      // "exact_fft": never use the one-limb kernel
+    bool exact_once = false;     // set while a call is repeated after a guard trip
+    int64_t one_limb_min = 0;    // launches of at least this many gate instances use the one-limb kernel
+    double guard_max = 0;        // largest rounding deviation seen by the one-limb kernel (of 0.5)
+    int64_t guard_reruns = 0;    // calls repeated on the two-limb kernel
+    int cus = 0;
     bool use_w64 = false;
     bool force_generic_ks = false;
     int32_t* ksk = nullptr;
@@ -541,9 +551,16 @@ void Evaluator::init() {
     {
         int cus = 0;
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        d_->cus = cus;
         d_->br_wide_max = cus;  // one workgroup of the wide kernel fills a CU
-        resident_gates_ = 4 * cus;  // k_blind_rotate_w2: 2 waves per gate, 256 VGPRs, 35.8 KB of LDS -> 4 workgroups per CU
+        // k_blind_rotate_w1: one wave per gate, 256 VGPRs -> 2 per SIMD = 8 gates per CU
+        // (k_blind_rotate_w2, "exact_fft": 2 waves per gate, 35.8 KB of LDS -> 4 per CU)
+        resident_gates_ = 8 * cus;
+        d_->one_limb_min = 2 * cus + 1;  // measured: from ~2 gates per CU on, one wave per gate finishes a launch sooner than two waves on two limbs
         if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
+        if (const char* e = getenv("IEACHE_ONE_LIMB_MIN")) d_->one_limb_min = atoll(e);
+        if (const char* e = getenv("IEACHE_EXACT_FFT")) d_->exact_fft = atoi(e) != 0;
+        if (d_->exact_fft) resident_gates_ = 4 * cus;
     }
     d_->p = p;
     DevKeys& K = d_->K;
@@ -608,6 +625,8 @@ void Evaluator::destroy() {
     (void)hipFree(d_->bkf);
     (void)hipFree(d_->bkf_w64);
     (void)hipFree(d_->tw_w64);
+    (void)hipFree(d_->bkf1_w64);
+    (void)hipFree(d_->fft_guard);
     (void)hipFree(d_->ksk);
     (void)hipFree(d_->twist);
     (void)hipFree(d_->wtab);
@@ -655,8 +674,18 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 1 && value <= 4096) {
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 12) {
+    } else if (name == "br_variant" && value >= 0 && value <= 17) {
         d_->br_variant = (int32_t)value;
+    } else if (name == "exact_fft" && (value == 0 || value == 1)) {
+        d_->exact_fft = value != 0;
+        resident_gates_ = (d_->exact_fft ? 4 : 8) * d_->cus;
+    } else if (name == "one_limb_min" && value >= 0) {
+        d_->one_limb_min = value;
+    } else if (name == "fft_guard_inject" && value == 1 && d_->fft_guard) {
+        // test hook: the next call finds the guard tripped and repeats itself on the two-limb kernel
+        const unsigned one = 1;
+        HIP_CHECK(hipSetDevice(device_));
+        HIP_CHECK(hipMemcpy(d_->fft_guard, &one, sizeof one, hipMemcpyHostToDevice));
     } else {
         return false;
     }
@@ -664,7 +693,9 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
 }
 
 std::string Evaluator::kernel_variant() const {
-    return (w64::supported(p_) && !force_generic_) ? "w2x64-radix8-registers" : "generic-radix2";
+    if (!w64::supported(p_) || force_generic_) return "generic-radix2";
+    // the kernel wide launches take: one wave per gate on the one-limb spectrum, or ("exact_fft") two waves on two limbs
+    return d_->exact_fft ? "w2x64-radix8-registers" : "w1x64-radix8-onelimb";
 }
 
 void Evaluator::load_keys_host(const Torus32* bk, const Torus32* ksk) {
@@ -709,6 +740,13 @@ void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
             HIP_CHECK(hipGetLastError());
         }
         w64::prepare_spectrum(p_, d_bk, d_->bkf_w64, stream_);
+        HIP_CHECK(hipGetLastError());
+        if (!d_->bkf1_w64) HIP_CHECK(hipMalloc(&d_->bkf1_w64, w64::spectrum1_elems(p_) * sizeof(double2)));
+        if (!d_->fft_guard) {
+            HIP_CHECK(hipMalloc(&d_->fft_guard, 2 * sizeof(unsigned)));
+            HIP_CHECK(hipMemsetAsync(d_->fft_guard, 0, 2 * sizeof(unsigned), stream_));
+        }
+        w64::prepare_spectrum1(p_, d_bk, d_->bkf1_w64, stream_);
         HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_pad_rows, dim3(2048), dim3(256), 0, stream_, d_ksk, d_->ksk, (int64_t)ks_rows, p_.n + 1,
@@ -757,10 +795,21 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
             HIP_CHECK(hipMalloc(&d->br_state, items * w64::state_bytes_per_item(p)));
             d->br_state_items = items;
         }
-        if (d->br_variant == 0 && cnt <= d->br_wide_max)
-            return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, w64::bara_stride(p), w64::kVariantWide,
-                               d->tw_w64, stream);
-        return w64::launch(p, d->K, d->bkf_w64, w, cnt, d->br_state, ext, steps, dbg_acc, d->br_slice, d->br_variant, d->tw_w64, stream);
+        // br_variant 0 = by launch size: the 2L-waves-per-gate kernel for a handful of gates, the two-wave two-limb kernel while
+        // every gate is resident at once, the one-wave one-limb kernel (guarded) for wide launches
+        int32_t variant = d->br_variant, slice = d->br_slice;
+        if (variant == 0) {
+            if (cnt <= d->br_wide_max) {
+                variant = w64::kVariantWide;
+                slice = w64::bara_stride(p);
+            } else if (!d->exact_fft && !d->exact_once && cnt >= d->one_limb_min) {
+                variant = w64::kVariantOneLimb;
+            }
+        } else if (d->exact_once && variant >= w64::kVariantOneLimb) {
+            variant = 0;
+        }
+        return w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, w, cnt, d->br_state, ext, steps, dbg_acc, slice, variant,
+                           d->tw_w64, stream);
     }
     else
         hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,
@@ -824,8 +873,81 @@ static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, W
     if (stats) stats->bootstraps += items;
 }
 
+// After a synchronous call: fold the one-limb kernel's guard record into the context and tell whether the call has to be
+// repeated on the two-limb kernel (some launch saw a coefficient further than kGuardLimit from an integer).
+bool Evaluator::fft_guard_tripped() {
+    if (!d_->fft_guard) return false;
+    unsigned h[2] = {0, 0};
+    HIP_CHECK(hipMemcpy(h, d_->fft_guard, sizeof h, hipMemcpyDeviceToHost));
+    float m;
+    memcpy(&m, &h[1], sizeof m);
+    if ((double)m > d_->guard_max) d_->guard_max = (double)m;
+    if (h[0] == 0) return false;
+    HIP_CHECK(hipMemset(d_->fft_guard, 0, sizeof(unsigned)));  // the count only; the maximum stays
+    return true;
+}
+
+double Evaluator::fft_guard_max() const { return d_->guard_max; }
+int64_t Evaluator::fft_guard_reruns() const { return d_->guard_reruns; }
+
+namespace {
+bool overlaps(const Torus32* a, size_t na, const Torus32* b, size_t nb) {
+    return a && b && a < b + nb && b < a + na;
+}
+// Repeats `once` on the two-limb kernel when the guard tripped; the first attempt's time stays in the stats, its counts do not.
+template <class F>
+void run_guarded(Evaluator& ev, bool* exact_once, int64_t* reruns, bool inputs_intact, EvalStats* stats, F&& once) {
+    const EvalStats before = stats ? *stats : EvalStats{};
+    once();
+    if (!ev.fft_guard_tripped()) return;
+    if (!inputs_intact)
+        throw std::runtime_error("FFT rounding guard tripped and the output overlaps the inputs: repeat the call with option exact_fft=1");
+    (*reruns)++;
+    EvalStats first{};
+    if (stats) {
+        first = *stats;
+        *stats = before;
+    }
+    *exact_once = true;
+    try {
+        once();
+    } catch (...) {
+        *exact_once = false;
+        throw;
+    }
+    *exact_once = false;
+    if (stats) stats->total_ms += first.total_ms - before.total_ms;
+}
+}  // namespace
+
 void Evaluator::gates_device(int32_t type, size_t count, const Torus32* d_a, const Torus32* d_b, Torus32* d_out,
                              EvalStats* stats) {
+    const size_t len = count * (size_t)d_->K.stride;
+    run_guarded(*this, &d_->exact_once, &d_->guard_reruns, !overlaps(d_out, len, d_a, len) && !overlaps(d_out, len, d_b, len), stats,
+                [&] { gates_device_once(type, count, d_a, d_b, d_out, stats); });
+}
+
+void Evaluator::mux_device(size_t count, const Torus32* d_a, const Torus32* d_b, const Torus32* d_c, Torus32* d_out,
+                           EvalStats* stats) {
+    const size_t len = count * (size_t)d_->K.stride;
+    run_guarded(*this, &d_->exact_once, &d_->guard_reruns,
+                !overlaps(d_out, len, d_a, len) && !overlaps(d_out, len, d_b, len) && !overlaps(d_out, len, d_c, len), stats,
+                [&] { mux_device_once(count, d_a, d_b, d_c, d_out, stats); });
+}
+
+void Evaluator::eval_circuit_device(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out, EvalStats* stats) {
+    const size_t stride = (size_t)d_->K.stride;
+    run_guarded(*this, &d_->exact_once, &d_->guard_reruns,
+                !overlaps(d_out, batch * c.outputs.size() * stride, d_in, batch * (size_t)c.n_inputs * stride), stats,
+                [&] { eval_circuit_device_once(c, batch, d_in, d_out, stats); });
+}
+
+void Evaluator::debug_blind_rotate(size_t count, const Torus32* d_x, Torus32* d_acc, int32_t steps) {
+    run_guarded(*this, &d_->exact_once, &d_->guard_reruns, true, nullptr, [&] { debug_blind_rotate_once(count, d_x, d_acc, steps); });
+}
+
+void Evaluator::gates_device_once(int32_t type, size_t count, const Torus32* d_a, const Torus32* d_b, Torus32* d_out,
+                                  EvalStats* stats) {
     if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
     HIP_CHECK(hipSetDevice(device_));
     if (count == 0) return;
@@ -852,8 +974,8 @@ void Evaluator::gates_device(int32_t type, size_t count, const Torus32* d_a, con
 }
 
 // bootsMUX (boot-gates.cpp): two blind rotations per gate, their extracted samples added, one key switch
-void Evaluator::mux_device(size_t count, const Torus32* d_a, const Torus32* d_b, const Torus32* d_c, Torus32* d_out,
-                           EvalStats* stats) {
+void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32* d_b, const Torus32* d_c, Torus32* d_out,
+                                EvalStats* stats) {
     if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
     HIP_CHECK(hipSetDevice(device_));
     if (count == 0) return;
@@ -912,8 +1034,8 @@ void Evaluator::mux_device(size_t count, const Torus32* d_a, const Torus32* d_b,
     }
 }
 
-void Evaluator::eval_circuit_device(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
-                                    EvalStats* stats) {
+void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
+                                         EvalStats* stats) {
     if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
     HIP_CHECK(hipSetDevice(device_));
     if (batch == 0) return;
@@ -972,7 +1094,7 @@ void Evaluator::eval_circuit_device(const Circuit& c, size_t batch, const Torus3
     }
 }
 
-void Evaluator::debug_blind_rotate(size_t count, const Torus32* d_x, Torus32* d_acc, int32_t steps) {
+void Evaluator::debug_blind_rotate_once(size_t count, const Torus32* d_x, Torus32* d_acc, int32_t steps) {
     if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
     HIP_CHECK(hipSetDevice(device_));
     WorkDesc W{};

@@ -121,6 +121,7 @@ def lib():
     L.ieache_ctx_set_chunk.argtypes = [vp, C.c_int64]
     L.ieache_ctx_force_generic.argtypes = [vp, C.c_int]
     L.ieache_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.ieache_ctx_fft_guard.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.ieache_ctx_kernel_variant.restype = C.c_char_p
     L.ieache_ctx_kernel_variant.argtypes = [vp]
     L.ieache_circuit_info_get.argtypes = [C.c_int, C.c_int, C.POINTER(CircuitInfo)]
@@ -254,6 +255,13 @@ class Context:
     @property
     def kernel_variant(self):
         return lib().ieache_ctx_kernel_variant(self.h).decode()
+
+    def fft_guard(self):
+        """(largest distance to an integer the one-limb blind rotation rounded away -- 0.5 would be a wrong bit --,
+        calls repeated on the two-limb kernel because a launch exceeded 1/16)."""
+        m, r = C.c_double(0), C.c_int64(0)
+        check(lib().ieache_ctx_fft_guard(self.h, C.byref(m), C.byref(r)))
+        return m.value, r.value
 
     def set_chunk(self, items):
         check(lib().ieache_ctx_set_chunk(self.h, items))

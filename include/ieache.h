@@ -151,13 +151,20 @@ void* ieache_ctx_stream(const ieache_ctx* ctx);
 /* make the context's stream wait for the work queued so far on `hip_stream`
  * (hipStream_t as void*; NULL = the default stream) -- see "Streams" above */
 int ieache_ctx_wait_stream(ieache_ctx* ctx, void* hip_stream);
+/* The wide-launch blind rotation multiplies with ONE FP64 transform of the 32-bit key coefficients, as libtfhe does
+ * (lwe-bootstrapping-functions-fft.cpp -> tGswFFTExternMulToTLwe), instead of the provably exact two-limb transform:
+ * its rounded sums carry ~2^-9 of error, and the kernel records how far from an integer they came.
+ * max_deviation: the largest distance seen by this context (0.5 would flip a bit; a launch above 1/16 makes the call
+ * repeat itself on the two-limb kernel, counted in reruns).  Option "exact_fft" = 1 (or IEACHE_EXACT_FFT=1) uses the
+ * two-limb kernel always.  Either pointer may be NULL. */
+int ieache_ctx_fft_guard(const ieache_ctx* ctx, double* max_deviation, int64_t* reruns);
 /* same contract as ieache_cloud_run but with this context's resident key */
 int ieache_ctx_cloud_run(ieache_ctx* ctx, const char* workdir);
 /* tuning / test knobs */
 int ieache_ctx_set_chunk(ieache_ctx* ctx, int64_t gate_instances_per_launch);
 int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
 /* named knobs: "chunk", "force_generic", "ks_sliced_min", "ks_gates", "ks_slice", "ks_batch_min",
- * "br_slice", "br_wide_max", "br_variant" (see csrc/evaluator.h), and
+ * "br_slice", "br_wide_max", "br_variant", "exact_fft", "one_limb_min" (see csrc/evaluator.h), and
  * "level_quantum" (0/1, default 1: the slack-balanced circuits -- 64/128-bit multipliers -- get a level
  * width that makes level x batch a whole number of resident-workgroup rounds; same DAG and output bits, more
  * levels of exactly-full launches when the batch is small), and

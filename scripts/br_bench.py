@@ -7,7 +7,7 @@ from ieache_amd import tools
 p = ia.default_params()
 k = tools.keygen_raw(p, (1, 2, 3))
 ctx = ia.Context.from_arrays(p, k["bk"], k["ksk"])
-for opt in ("br_variant", "br_slice", "ks_batch_min", "ks_sliced_min", "ks_slice", "ks_gates"):  # e.g. BR_VARIANT=7 BR_SLICE=630
+for opt in ("br_variant", "br_slice", "exact_fft", "one_limb_min", "br_wide_max", "ks_batch_min", "ks_sliced_min", "ks_slice", "ks_gates"):  # e.g. BR_VARIANT=7 BR_SLICE=630
     if os.environ.get(opt.upper()):
         ctx.set_option(opt, int(os.environ[opt.upper()]))
 rng = np.random.default_rng(0)
@@ -26,4 +26,4 @@ for count in counts:
     ok = np.array_equal(tools.decrypt_bits(p, k["lwe_key"], out), bits[0][:count] & bits[1][:count])
     print("variant", os.environ.get("BR_VARIANT", os.environ.get("IEACHE_BR_VARIANT", "0")), "slice", os.environ.get("BR_SLICE", "16"), ctx.kernel_variant, "count", count, "ok", ok,
           "BR ms %.2f (%.0f gates/s)  KS ms %.2f (%.0f gates/s)" % (best.blind_rotate_ms, count / best.blind_rotate_ms * 1e3,
-          best.keyswitch_ms, count / best.keyswitch_ms * 1e3), flush=True)
+          best.keyswitch_ms, count / best.keyswitch_ms * 1e3), "guard", ctx.fft_guard(), flush=True)

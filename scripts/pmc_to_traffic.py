@@ -5,7 +5,10 @@ profiles/traffic.json, the committed counter evidence bench.py's roofline reads.
 HBM bytes as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) is doubled
 (wide coalesced reads are tallied at 64 B per 128-B request), WRITE_SIZE (KB) taken as is, separate passes.
 
-  python scripts/pmc_to_traffic.py profiles/r2_a_pmc_summary.txt [gates_per_launch=8192] [cmux_steps_per_launch=16]
+  python scripts/pmc_to_traffic.py profiles/r2_f_pmc_summary.txt [gates_per_launch=8192] [cmux_steps_per_launch=16] [kernel key]
+
+The kernel key is what ieache_ctx_kernel_variant() reports ("w1x64-radix8-onelimb", the default, or
+"w2x64-radix8-registers" with exact_fft); the other kernel's entry in traffic.json is kept.
 """
 import json
 import os
@@ -16,6 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 summary = sys.argv[1]
 gates = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+key = sys.argv[4] if len(sys.argv) > 4 else "w1x64-radix8-onelimb"
+# FP64 instructions per gate and CMux step, counted in the kernels' ISA (scripts/isa_count.py)
+KERNELS = {"w1x64-radix8-onelimb": ("k_blind_rotate_w1<3,7,guard>", 2561), "w2x64-radix8-registers": ("k_blind_rotate_w2<3,7>", 3368)}
 vals = {}
 for line in open(summary):
     m = re.match(r"(BR|KS) (\S+)\s+n=(\d+) avg=([0-9.e+-]+)", line)
@@ -28,9 +34,11 @@ def hbm(k):
     return (2.0 * vals[(k, "FETCH_SIZE")] + vals[(k, "WRITE_SIZE")]) * 1024.0
 
 
-out = {
-    "w2x64-radix8-registers": {
-        "kernel": "k_blind_rotate_w2<3,7>", "pmc_summary": rel,
+path = os.path.join(ROOT, "profiles", "traffic.json")
+out = json.load(open(path)) if os.path.exists(path) else {}
+out.update({
+    key: {
+        "kernel": KERNELS[key][0], "fp64_insts_per_gate_step": KERNELS[key][1], "pmc_summary": rel,
         "source": rel + " (scripts/pmc_passes.sh: separate rocprofv3 --pmc passes over scripts/br_bench.py %d)" % gates,
         "gates_per_launch": gates, "cmux_steps_per_launch": steps,
         "FETCH_SIZE_KB_avg": vals[("BR", "FETCH_SIZE")], "WRITE_SIZE_KB_avg": vals[("BR", "WRITE_SIZE")],
@@ -50,6 +58,6 @@ out = {
         "hbm_bytes_per_launch": hbm("KS"),
         "l2_hit_rate": vals[("KS", "TCC_HIT_sum")] / (vals[("KS", "TCC_HIT_sum")] + vals[("KS", "TCC_MISS_sum")]),
     },
-}
-json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-print(json.dumps(out["w2x64-radix8-registers"], indent=1))
+})
+json.dump(out, open(path, "w"), indent=1)
+print(json.dumps(out[key], indent=1))

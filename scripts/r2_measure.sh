@@ -12,6 +12,7 @@ echo "bench under rocprof done"; tail -c 600 $OUT/bench_rocprof.json
 find $OUT/stats -name "*kernel_stats.csv" | head -3
 bash scripts/pmc_passes.sh $OUT/pmc python3 scripts/br_bench.py 8192 > $OUT/pmc.log 2>&1 || echo "pmc failed"
 tail -30 $OUT/pmc/summary.txt || true
-for v in 0 5 6; do BR_VARIANT=$v python3 scripts/br_bench.py 8192 16384; done > $OUT/variants.txt 2>&1
-for s in 12 16 20 21 32; do BR_SLICE=$s python3 scripts/br_bench.py 8192; done >> $OUT/variants.txt 2>&1
+for v in 13 14 15; do BR_VARIANT=$v python3 scripts/br_bench.py 8192 16384; done > $OUT/variants.txt 2>&1
+EXACT_FFT=1 python3 scripts/br_bench.py 8192 16384 >> $OUT/variants.txt 2>&1
+for s in 8 32; do BR_SLICE=$s python3 scripts/br_bench.py 8192; done >> $OUT/variants.txt 2>&1
 cat $OUT/variants.txt

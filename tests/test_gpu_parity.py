@@ -605,6 +605,19 @@ def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
     assert (tmp_path / "averagestandard.txt").exists()  # MUL timing log (cloud.c:2467-2471)
 
 
+def _inplace_gates(ia, ctx, a, b):
+    """gates_device with the output written over the first operand."""
+    import torch
+    stride = ctx.lwe_stride
+    da = torch.zeros((a.shape[0], stride), dtype=torch.int32, device="cuda")
+    db = torch.zeros_like(da)
+    da[:, : a.shape[1]] = torch.from_numpy(a).cuda()
+    db[:, : b.shape[1]] = torch.from_numpy(b).cuda()
+    torch.cuda.synchronize()
+    ctx.gates_device(ia.GATE_AND, a.shape[0], da.data_ptr(), db.data_ptr(), da.data_ptr())
+    return da.cpu().numpy()[:, : a.shape[1]]
+
+
 def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     """Fast (two-waves-per-gate, sliced), latency (2L-waves-per-gate) and generic kernels, every slice
     size, both key-switch kernels: all must produce identical bits (and the oracle's)."""
@@ -629,7 +642,35 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         ctx.set_option("br_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:600], b[:600]), ref[:600]), sl
     ctx.set_option("br_slice", 16)
+    # one wave per gate on the one-limb spectrum (the default for wide launches, which `ref` above took): with and without
+    # the guard arithmetic, forward transposes through LDS / cross-lane, early BK requests; ragged last workgroup of 4 gates
+    for variant in (13, 14, 15, 16, 17):
+        ctx.set_option("br_variant", variant)
+        assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), variant
+    ctx.set_option("br_variant", 13)
+    for sl in (1, 5, 64):
+        ctx.set_option("br_slice", sl)
+        assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), sl
+    ctx.set_option("br_slice", 16)
     ctx.set_option("br_variant", 0)
+    dev, reruns = ctx.fft_guard()
+    assert 0 < dev < 1 / 16 and reruns == 0                # rounding stayed far from the 0.5 that would flip a bit
+    ctx.set_option("exact_fft", 1)                         # two-limb (provably exact) kernel for every launch size
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
+    ctx.set_option("exact_fft", 0)
+    ctx.set_option("fft_guard_inject", 1)                  # a tripped guard makes the call repeat itself on the two-limb kernel
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
+    assert ctx.fft_guard()[1] == 1
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref) and ctx.fft_guard()[1] == 1
+    ctx.set_option("fft_guard_inject", 1)
+    with pytest.raises(ia.IeacheError, match="overlaps"):  # in-place call: the inputs are gone, so it cannot be repeated
+        _inplace_gates(ia, ctx, a[:600], b[:600])
+    ctx.set_option("one_limb_min", 0)                      # one-limb kernel down to a single gate
+    ctx.set_option("br_wide_max", 0)
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a[:1], b[:1]), ref[:1])
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a[:7], b[:7]), ref[:7])
+    ctx.set_option("one_limb_min", 513)
+    ctx.set_option("br_wide_max", 256)
     # policy: launches of <= br_wide_max gates take the wide kernel by themselves (default = CU count)
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:200], b[:200]), ref[:200])
     ctx.set_option("br_wide_max", 0)
@@ -660,7 +701,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
     ctx.force_generic(False)
     with pytest.raises(ia.IeacheError):
-        ctx.set_option("br_variant", 13)
+        ctx.set_option("br_variant", 18)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("br_slice", 4097)
     with pytest.raises(ia.IeacheError):
@@ -742,18 +783,18 @@ def test_carry_save_multiplier_decrypts_identically(ia, gpu_ctx, tmp_path):
 
 
 def test_batch_aware_level_width_same_bits(ia, gpu_ctx):
-    """"level_quantum" re-levels the 64/128-bit multipliers for the batch at hand (here 16 expressions: levels of 64 gates
-    = exactly one round of 1 024 resident workgroups); the DAG is the same, so every output sample is."""
+    """"level_quantum" re-levels the 64/128-bit multipliers for the batch at hand (here 32 expressions: levels of 64 gates
+    = exactly one round of the 2 048 gates the one-wave kernel keeps resident); the DAG is the same, so every output sample is."""
     kb, ctx = gpu_ctx(4, 1024)
     rng = np.random.default_rng(16)
-    vals = [(int.from_bytes(rng.bytes(8), "little"), int.from_bytes(rng.bytes(8), "little")) for _ in range(16)]
+    vals = [(int.from_bytes(rng.bytes(8), "little"), int.from_bytes(rng.bytes(8), "little")) for _ in range(32)]
     inp = _inputs(kb, 4, 64, vals, 33)
-    resident = 4 * 256
-    cap = ia.circuit_level_cap(4, 64, 16, resident)
+    resident = 8 * 256
+    cap = ia.circuit_level_cap(4, 64, 32, resident)
     assert cap == 64
     st = ia.Stats()
     out = ctx.eval_batch(4, 64, inp, st)
-    assert st.levels == ia.circuit_info(4, 64, level_cap=cap).sched_levels > 449 and st.bootstraps == 16 * 35296
+    assert st.levels == ia.circuit_info(4, 64, level_cap=cap).sched_levels > 449 and st.bootstraps == 32 * 35296
     ctx.set_option("level_quantum", 0)
     try:
         st0 = ia.Stats()
@@ -785,6 +826,18 @@ def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
         r1 = kb.ck.gate("xor", a[i], b[i])
         assert np.array_equal(r1, first[i]), i
         assert np.array_equal(kb.ck.gate("and", r1, b[i]), second[i]), i
+    # the same gates on the kernel wide launches take (one wave per gate, one-limb spectrum, rounding guard) and on the
+    # two-wave two-limb kernel: 24 gates go to the latency kernel unless told otherwise
+    for opts in ({"one_limb_min": 0, "br_wide_max": 0}, {"exact_fft": 1, "br_wide_max": 0}):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        f2 = ctx.gates(ia.GATE_XOR, a, b)
+        assert np.array_equal(f2, first) and np.array_equal(ctx.gates(ia.GATE_AND, f2, b), second), opts
+    dev, reruns = ctx.fft_guard()
+    assert 0 < dev < 1 / 32 and reruns == 0
+    ctx.set_option("exact_fft", 0)
+    ctx.set_option("one_limb_min", 513)
+    ctx.set_option("br_wide_max", 256)
 
 
 def test_full_config_add16_batch4096_decrypts(ia, gpu_ctx):
