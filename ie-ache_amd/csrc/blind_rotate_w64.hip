@@ -223,8 +223,13 @@ constexpr int kTile = 8 * 72;  // double2 elements per tile (9216 B)
 // ILV: issue each ds_write right behind the multiply that produces its data instead of as a burst of 8 after
 // all of them (left alone the compiler clusters the stores): the wave's own LDS-store issue (~13 cycles each on
 // CDNA4) then runs under its next twiddle multiply instead of stalling its instruction stream.
-template <bool WSYNC, int XLANE = 0, int ILV = 0>
-__device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// MID: called once the first inter-pass twiddles are consumed (their 32 VGPRs are free from there on): the place to
+// request data the caller needs right after the transform
+template <bool WSYNC, int XLANE = 0, int ILV = 0, class MID = NoHook, bool MID_LATE = false>
+__device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R, MID mid = MID()) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
     const int blk = hi * 72 + lo;  // (h, l) = (lane>>3, lane&7)
@@ -266,6 +271,11 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = cmulx<false>(x[k], tA[k]);  // * tL * w512^(lane*k0)
+    if (!std::is_same<MID, NoHook>::value && !MID_LATE) {
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
     if (XLANE & 1) {
@@ -281,6 +291,11 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
     dft8<false>(x);                          // over p1 -> k1 ; lane = 8*k0 + p0
 #pragma unroll
     for (int k = 1; k < 8; k++) x[k] = cmulx<false>(x[k], tB[k]);  // * w64^(p0*k1)
+    if (!std::is_same<MID, NoHook>::value && MID_LATE) {  // ... or once the second twiddles are consumed too
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (XLANE & 2) {
         xlane_lo(x, lane);                                          // reg k1 <-> lane bits 0..2: lane = (k0, k1), reg = p0
     } else {
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 // dynamic LDS: sT [4][kTile] double2 | tw [kTwElems] double2 | acc [4][2][1024] int32     (78 848 B -> 2 per CU)
 constexpr int kW1Gates = 4;
 constexpr float kGuardLimit = 0.0625f;
-template <int L, int BGBIT, bool GUARD, int XLANE = 1, bool EARLYB = false>
+template <int L, int BGBIT, bool GUARD, int XLANE = 1, int EARLYB = 0>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K, const double2* __restrict__ bkf1,
                                                                       const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                       int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -759,13 +774,23 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
                 x[r] = r == 0 ? make_double2((double)e0, (double)e1)
                               : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
-            if (EARLYB) {
+            if (EARLYB == 1) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) bB[k] = brow[(8 + k) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
-            fft512_forward<true, XLANE, 0>(x, sT, lane, R);
-            if (!EARLYB) {
+            if (EARLYB >= 2) {
+                // the second block is requested inside the transform, into the registers its twiddles leave
+                // (2: after the first inter-pass twiddles, 3: after the second)
+                auto req = [&]() {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) bB[k] = brow[(8 + k) * 64];
+                };
+                fft512_forward<true, XLANE, 0, decltype(req), EARLYB == 3>(x, sT, lane, R, req);
+            } else {
+                fft512_forward<true, XLANE, 0>(x, sT, lane, R);
+            }
+            if (EARLYB == 0) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) bB[k] = brow[(8 + k) * 64];   // -> output polynomial 1
             }
@@ -1146,7 +1171,9 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         case 1: IEACHE_W1(false) break;          // no guard arithmetic (measurement)
         case 2: IEACHE_W1(true, 0) break;        // forward transposes through LDS
         case 3: IEACHE_W1(true, 3) break;        // both forward transposes cross-lane
-        case 4: IEACHE_W1(true, 1, true) break;  // both BK blocks of a row requested before its transform
+        case 4: IEACHE_W1(true, 1, 1) break;     // both BK blocks of a row requested before its transform
+        case 5: IEACHE_W1(true, 1, 2) break;     // the second one from inside the transform
+        case 6: IEACHE_W1(true, 1, 3) break;
         default: IEACHE_W1(true) break;
     }
 #undef IEACHE_W1
@@ -1165,7 +1192,7 @@ int32_t default_slice() {
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
-    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 4;
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 6;
     if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
