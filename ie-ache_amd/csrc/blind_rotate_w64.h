@@ -48,6 +48,9 @@ constexpr int32_t kVariantWide = 7;
 // wide launches), 14 = the same without the guard arithmetic (measurement only).  Bit-identical to the two-limb kernels
 // as long as the guard stays silent.
 constexpr int32_t kVariantOneLimb = 13;
+// 20 = two waves per gate on the one-limb spectrum (k_blind_rotate_w2s; the evaluator's choice for mid-size launches),
+// 21 = the same without the guard arithmetic
+constexpr int32_t kVariantOneLimbTwoWaves = 20;
 
 }  // namespace w64
 }  // namespace ieache

@@ -859,6 +859,144 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
     }
 }
 
+// ---- K3 (+K4), mid-size launches: two waves per gate instance on the ONE-limb spectrum ----
+// Between the latency kernel (a handful of gates) and k_blind_rotate_w1 (more gates than the chip holds one-per-SIMD-slot)
+// lie launches of a few hundred to ~1 000 gates: deep circuits at small batches, cloudd's batches.  One wave per gate
+// leaves SIMD slots empty there, and the step of a lone wave is a serial chain of 8 transforms.  This is
+// k_blind_rotate_w2's mapping (wave w decomposes polynomial w and owns output polynomial w; spectra cross through the
+// producing wave's tile; two barriers per digit row) on k_blind_rotate_w1's arithmetic: one accumulator per wave,
+// 3 forward + 1 inverse transform and 6 row products per wave and step, guarded rounding.
+// dynamic LDS as k_blind_rotate_w2: sT [2][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32
+template <int L, int BGBIT, bool GUARD>
+__global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const double2* __restrict__ bkf1,
+                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                            int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
+                                                            unsigned* guard, const double2* __restrict__ gtw) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* sT_all = reinterpret_cast<double2*>(smem);
+    double2* sTw = sT_all + 2 * kTile;
+    int32_t* acc = reinterpret_cast<int32_t*>(sTw + kTwElems);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;
+    const double2* sTp = sT_all + (wave ^ 1) * kTile;
+    const int64_t item = (int64_t)blockIdx.x;
+    const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    load_twiddles(sTw, gtw, tid, 128);
+    const LaneRoots R = make_roots(sTw, lane);
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[128 * r + tid] = src[128 * r + tid];
+    }
+    __syncthreads();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+    int32_t* accw = acc + wave * kN;  // the polynomial this wave decomposes and updates
+    double dev_max = 0.0;
+
+    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
+        if (a == 0) continue;  // workgroup-uniform
+        // BK_i rows [2L][2][8][64]; this wave reads output block `wave` of every row
+        const double2* __restrict__ bki = bkf1 + (size_t)i * (2 * L * 2 * kM) + (size_t)wave * kM + lane;
+        double2 s[8];
+        uint32_t v0[8], v1[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int32_t j = 64 * r + lane;
+            v0[r] = (((uint32_t)rot_coef(accw, j, a, kN) - (uint32_t)accw[j]) + dec_offset) ^ dec_offset;
+            v1[r] = (((uint32_t)rot_coef(accw, j + kM, a, kN) - (uint32_t)accw[j + kM]) + dec_offset) ^ dec_offset;
+        }
+        auto digit_row = [&](const int q, auto first) {
+            constexpr bool FIRST = decltype(first)::value;
+            const int sh = 32 - (q + 1) * BGBIT;
+            const double2* __restrict__ bown = bki + (size_t)(wave * L + q) * (2 * kM);
+            const double2* __restrict__ bpar = bki + (size_t)((wave ^ 1) * L + q) * (2 * kM);
+            double2 x[8], bA[8], bC[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) bA[k] = bown[k * 64];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);
+                const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
+                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto req = [&]() {  // the partner row's block, requested once the transform's twiddle registers are free
+#pragma unroll
+                for (int k = 0; k < 8; k++) bC[k] = bpar[k * 64];
+            };
+            fft512_forward<true, 1, 0, decltype(req), true>(x, sT, lane, R, req);
+            // hand the spectrum to the partner wave through our own (now idle) tile
+#pragma unroll
+            for (int k = 0; k < 8; k++) sT[k * 64 + lane] = x[k];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[k] = FIRST ? cmulx<false>(x[k], bA[k])
+                             : make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[k].x)),
+                                            fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[k].y)));
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = sTp[k * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[k] = make_double2(fma(x[k].x, bC[k].x, fma(-x[k].y, bC[k].y, s[k].x)),
+                                    fma(x[k].x, bC[k].y, fma(x[k].y, bC[k].x, s[k].y)));
+            __syncthreads();  // partner has read our tile before the next transform reuses it
+        };
+        digit_row(0, std::true_type{});
+#pragma unroll 1
+        for (int q = 1; q < L; q++) digit_row(q, std::false_type{});
+        fft512_inverse<true, 0>(s, sT, lane, R);
+        uint32_t* accu = reinterpret_cast<uint32_t*>(accw);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
+            const double t0 = z.x + kMagic, t1 = z.y + kMagic;
+            if (GUARD) {
+                dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
+                dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
+            }
+            const int32_t j = 64 * r + lane;
+            __hip_atomic_fetch_add(&accu[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&accu[j + kM], (uint32_t)__double2loint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        wave_sync();  // wave w reads and updates only polynomial w: nothing crosses waves here
+    }
+    __syncthreads();  // the epilogue below reads both polynomials with all threads
+    if (GUARD) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
+        }
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = tid; j <= kN; j += 128)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[128 * r + tid] = src[128 * r + tid];
+    }
+}
+
 // ---- K3 (+K4), latency-oriented: 2L waves per gate instance ----
 // For narrow levels (a single expression, the reference's own mode) the time of a level is the
 // LATENCY of one blind rotation, and two waves walking 3 forward + 2 inverse transforms one after
@@ -1167,6 +1305,15 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         hipLaunchKernelGGL((k_blind_rotate_w1<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
                            st_acc, items, i0, i1, e, guard, gtw);                                                               \
     }
+    if (sub == 7 || sub == 8) {  // two waves per gate on the one-limb spectrum (mid-size launches); 8 = without the guard arithmetic
+        const dim3 g2((unsigned)items), b2(128);
+        const size_t lds2 = (size_t)(2 * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
+        if (sub == 7)
+            hipLaunchKernelGGL((k_blind_rotate_w2s<L, BGBIT, true>), g2, b2, lds2, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
+        else
+            hipLaunchKernelGGL((k_blind_rotate_w2s<L, BGBIT, false>), g2, b2, lds2, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
+        return;
+    }
     switch (sub) {  // > 64 KiB of dynamic LDS has to be allowed explicitly, per instantiation
         case 1: IEACHE_W1(false) break;          // no guard arithmetic (measurement)
         case 2: IEACHE_W1(true, 0) break;        // forward transposes through LDS
@@ -1192,7 +1339,7 @@ int32_t default_slice() {
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
-    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 6;
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 8;
     if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);

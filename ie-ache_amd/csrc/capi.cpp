@@ -116,7 +116,7 @@ const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits, size_t batch = 0
     if (!base || !base->balanced_schedule || !ctx->level_quantum) return base;
     // slack-balanced circuits: level width chosen so that a level x this batch is a whole number of the
     // workgroup rounds the GPU holds at once (same DAG, same output bits, another level assignment)
-    const int cap = circuit_level_cap(*base, (int64_t)batch, ctx->eval->resident_gates());
+    const int cap = circuit_level_cap(*base, (int64_t)batch, ctx->eval->resident_gates(), ctx->eval->resident_gates_two_wave());
     const int mean = (int)((base->n_bootstraps + base->depth - 1) / base->depth);
     return cap > 0 && cap != mean ? fetch(cap) : base;
 }

@@ -622,7 +622,13 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool
     return true;
 }
 
-int32_t circuit_level_cap(const Circuit& base, int64_t batch, int32_t resident) {
+int32_t circuit_level_cap(const Circuit& base, int64_t batch, int32_t resident, int32_t resident_alt) {
+    // resident_alt: a second, smaller residency the evaluator also runs efficiently (the two-waves-per-gate kernel's 4 per
+    // CU below the one-wave kernel's 8 per CU): tried when the batch is too small to fill levels of the first
+    if (resident_alt > 0) {
+        const int32_t cap = circuit_level_cap(base, batch, resident, 0);
+        return cap > 0 ? cap : circuit_level_cap(base, batch, resident_alt, 0);
+    }
     const int64_t n_bootstraps = base.n_bootstraps;
     const int32_t asap_depth = base.depth;
     if (!base.balanced_schedule || batch <= 0 || resident <= 0 || asap_depth <= 0 || batch >= resident) return 0;

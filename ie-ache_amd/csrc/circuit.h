@@ -172,7 +172,7 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced = tru
 // the multiple of resident / gcd(resident, batch) nearest to the circuit's mean width, or 0 (= keep the mean) when
 // a level is under one round anyway or the batch already is a multiple of a round.
 // `base`: the circuit under its default schedule.
-int32_t circuit_level_cap(const Circuit& base, int64_t batch, int32_t resident);
+int32_t circuit_level_cap(const Circuit& base, int64_t batch, int32_t resident, int32_t resident_alt = 0);
 // number of input / output samples per expression of a circuit kind
 int32_t circuit_n_inputs(int32_t kind, int32_t bits);
 int32_t circuit_n_outputs(int32_t kind, int32_t bits);

@@ -38,6 +38,8 @@ public:
     // gate instances the blind-rotation kernel keeps resident at once (one workgroup each, 4 per CU): a launch
     // takes ceil(gate instances / this) rounds
     int resident_gates() const { return resident_gates_; }
+    // ... and by the two-waves-per-gate one-limb kernel that takes launches up to that size (0 when "exact_fft" leaves one size)
+    int resident_gates_two_wave() const { return resident_two_wave_; }
     // Orders everything launched later on the evaluator's stream after the work queued so far on
     // `producer` (the stream that wrote the key / input buffers handed over as device pointers).
     void wait_for_stream(hipStream_t producer);
@@ -83,7 +85,8 @@ public:
     // "br_wide_max" (launches of at most this many gate instances use the latency-oriented
     // 2L-waves-per-gate kernel; default = the device's CU count, 0 = never), "br_variant",
     // "exact_fft" (1 = two-limb blind rotation always), "one_limb_min" (launches of at least this many gate
-    // instances use the one-limb kernel; default 2 per CU + 1).
+    // instances use the one-limb kernels; default: one per CU + 1), "two_wave_max" (of those, launches up to this many
+    // gate instances take two waves per gate, k_blind_rotate_w2s; default 4 per CU).
     // Returns false for an unknown name or a value out of range.
     bool set_option(const std::string& name, int64_t value);
     std::string kernel_variant() const;
@@ -110,6 +113,7 @@ private:
     bool keys_loaded_ = false;
     bool force_generic_ = false;
     int resident_gates_ = 1024;
+    int resident_two_wave_ = 0;
     Impl* d_ = nullptr;
 };
 

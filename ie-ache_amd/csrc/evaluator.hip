@@ -493,7 +493,8 @@ struct Evaluator::Impl {
     unsigned* fft_guard = nullptr;  // [0] launches whose rounding deviation exceeded the limit, [1] max deviation (float bits)
     bool exact_fft = false;      // "exact_fft": never use the one-limb kernel
     bool exact_once = false;     // set while a call is repeated after a guard trip
-    int64_t one_limb_min = 0;    // launches of at least this many gate instances use the one-limb kernel
+    int64_t one_limb_min = 0;    // launches of at least this many gate instances use the one-limb kernels
+    int64_t two_wave_max = 0;    // ... the two-waves-per-gate one up to this many (4 per CU: all resident at once), the one-wave one above
     double guard_max = 0;        // largest rounding deviation seen by the one-limb kernel (of 0.5)
     int64_t guard_reruns = 0;    // calls repeated on the two-limb kernel
     int cus = 0;
@@ -556,11 +557,17 @@ void Evaluator::init() {
         // k_blind_rotate_w1: one wave per gate, 256 VGPRs -> 2 per SIMD = 8 gates per CU
         // (k_blind_rotate_w2, "exact_fft": 2 waves per gate, 35.8 KB of LDS -> 4 per CU)
         resident_gates_ = 8 * cus;
-        d_->one_limb_min = 2 * cus + 1;  // measured: from ~2 gates per CU on, one wave per gate finishes a launch sooner than two waves on two limbs
+        d_->one_limb_min = cus + 1;  // everything the latency kernel does not take
+        d_->two_wave_max = 4 * cus;
+        if (const char* e = getenv("IEACHE_TWO_WAVE_MAX")) d_->two_wave_max = atoll(e);
         if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
         if (const char* e = getenv("IEACHE_ONE_LIMB_MIN")) d_->one_limb_min = atoll(e);
         if (const char* e = getenv("IEACHE_EXACT_FFT")) d_->exact_fft = atoi(e) != 0;
-        if (d_->exact_fft) resident_gates_ = 4 * cus;
+        resident_two_wave_ = 4 * cus;
+        if (d_->exact_fft) {
+            resident_gates_ = 4 * cus;
+            resident_two_wave_ = 0;
+        }
     }
     d_->p = p;
     DevKeys& K = d_->K;
@@ -674,13 +681,16 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 1 && value <= 4096) {
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 19) {
+    } else if (name == "br_variant" && value >= 0 && value <= 21) {
         d_->br_variant = (int32_t)value;
     } else if (name == "exact_fft" && (value == 0 || value == 1)) {
         d_->exact_fft = value != 0;
         resident_gates_ = (d_->exact_fft ? 4 : 8) * d_->cus;
+        resident_two_wave_ = d_->exact_fft ? 0 : 4 * d_->cus;
     } else if (name == "one_limb_min" && value >= 0) {
         d_->one_limb_min = value;
+    } else if (name == "two_wave_max" && value >= 0) {
+        d_->two_wave_max = value;
     } else if (name == "fft_guard_inject" && value == 1 && d_->fft_guard) {
         // test hook: the next call finds the guard tripped and repeats itself on the two-limb kernel
         const unsigned one = 1;
@@ -803,7 +813,8 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
                 variant = w64::kVariantWide;
                 slice = w64::bara_stride(p);
             } else if (!d->exact_fft && !d->exact_once && cnt >= d->one_limb_min) {
-                variant = w64::kVariantOneLimb;
+                // while every gate fits a two-wave slot, two waves per gate finish a step sooner than one
+                variant = cnt <= d->two_wave_max ? w64::kVariantOneLimbTwoWaves : w64::kVariantOneLimb;
             }
         } else if (d->exact_once && variant >= w64::kVariantOneLimb) {
             variant = 0;

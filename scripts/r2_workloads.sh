@@ -2,7 +2,7 @@
 # Other workloads, latencies and serving on one MI355X (run through gpurun from the repo root)
 cd "$(dirname "$0")/.."
 O=gpurun_out/r2_work; mkdir -p $O
-VARIANTS="13 19 18" COUNTS="8192 16384" bash scripts/w1_sweep.sh > $O/w1_variants.txt 2>&1 || exit 1
+[ -n "$SKIP_SWEEP" ] || { VARIANTS="13 19 18" COUNTS="8192 16384" bash scripts/w1_sweep.sh > $O/w1_variants.txt 2>&1 || exit 1; }
 echo sweep done
 timeout -k 10 300 python bench.py --workload muladd64 --steps 1 --warmup 0 --no-cpu-baseline --mul32-leg off > $O/muladd64x128.json 2> $O/muladd64x128.err || exit 1
 echo muladd64 done

@@ -644,7 +644,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     ctx.set_option("br_slice", 16)
     # one wave per gate on the one-limb spectrum (the default for wide launches, which `ref` above took): with and without
     # the guard arithmetic, forward transposes through LDS / cross-lane, early BK requests; ragged last workgroup of 4 gates
-    for variant in (13, 14, 15, 16, 17, 18, 19):
+    for variant in (13, 14, 15, 16, 17, 18, 19, 20, 21):     # 20 / 21: two waves per gate on the one-limb spectrum
         ctx.set_option("br_variant", variant)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), variant
     ctx.set_option("br_variant", 13)
@@ -669,7 +669,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     ctx.set_option("br_wide_max", 0)
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:1], b[:1]), ref[:1])
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:7], b[:7]), ref[:7])
-    ctx.set_option("one_limb_min", 513)
+    ctx.set_option("one_limb_min", 257)
     ctx.set_option("br_wide_max", 256)
     # policy: launches of <= br_wide_max gates take the wide kernel by themselves (default = CU count)
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:200], b[:200]), ref[:200])
@@ -701,7 +701,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
     ctx.force_generic(False)
     with pytest.raises(ia.IeacheError):
-        ctx.set_option("br_variant", 20)
+        ctx.set_option("br_variant", 22)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("br_slice", 4097)
     with pytest.raises(ia.IeacheError):
@@ -828,7 +828,7 @@ def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
         assert np.array_equal(kb.ck.gate("and", r1, b[i]), second[i]), i
     # the same gates on the kernel wide launches take (one wave per gate, one-limb spectrum, rounding guard) and on the
     # two-wave two-limb kernel: 24 gates go to the latency kernel unless told otherwise
-    for opts in ({"one_limb_min": 0, "br_wide_max": 0}, {"exact_fft": 1, "br_wide_max": 0}):
+    for opts in ({"one_limb_min": 0, "br_wide_max": 0, "two_wave_max": 0}, {"two_wave_max": 1024}, {"exact_fft": 1}):
         for k, v in opts.items():
             ctx.set_option(k, v)
         f2 = ctx.gates(ia.GATE_XOR, a, b)
@@ -836,7 +836,7 @@ def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
     dev, reruns = ctx.fft_guard()
     assert 0 < dev < 1 / 32 and reruns == 0
     ctx.set_option("exact_fft", 0)
-    ctx.set_option("one_limb_min", 513)
+    ctx.set_option("one_limb_min", 257)
     ctx.set_option("br_wide_max", 256)
 
 
