@@ -51,6 +51,9 @@ constexpr int32_t kVariantOneLimb = 13;
 // 20 = two waves per gate on the one-limb spectrum (k_blind_rotate_w2s; the evaluator's choice for mid-size launches),
 // 21 = the same without the guard arithmetic
 constexpr int32_t kVariantOneLimbTwoWaves = 20;
+// 22 = 2L waves per gate, each wave one whole row of the one-limb spectrum (k_blind_rotate_wide1: the latency kernel's
+// one-limb form; any slice length up to n), 23 = the same without the guard arithmetic
+constexpr int32_t kVariantWideOneLimb = 22;
 
 }  // namespace w64
 }  // namespace ieache

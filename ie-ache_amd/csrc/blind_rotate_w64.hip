@@ -1183,6 +1183,142 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
 }
 
 
+// ---- K3 (+K4), latency-oriented on the ONE-limb spectrum: 2L waves per gate, every wave a whole row ----
+// k_blind_rotate_wide hands all 2L spectra to four output waves (two barriers, 192 KiB of LDS reads, 192 KiB of BK through
+// one CU per step).  The inverse transform is linear and every row's product digit_row (*) BK_row is itself an integer
+// polynomial, so here wave w keeps its spectrum in registers, multiplies it with BOTH output blocks of its own BK row,
+// inverse-transforms the two products itself (interleaved) and adds the rounded coefficients into the accumulator with
+// ds_add_u32 (addition mod 2^32 commutes).  No spectrum crosses waves; two barriers per step (accumulator read / written);
+// 96 KiB of BK per step, requested before the decomposition.  2L forward + 4L inverse transforms instead of 2L + 2, on
+// six waves that would otherwise wait for each other.  Each partial product is 1/2L of the full sum, so the rounding
+// margin of section 2 only grows; the guard is the same.
+// MEASURED (n = 630, one gate per CU): 3.9-4.1 ms per blind rotation against 3.35-3.67 ms for k_blind_rotate_wide -- six
+// waves on four SIMDs put two whole rows (~1 000 vector instructions each) on two of them, and that serial vector work
+// (8 k cycles per step) is longer than the hand-overs it removes.  Kept selectable (br_variant 22 / 23), not used by default.
+// dynamic LDS: sT [2L][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32 | bara [i1-i0] u16
+template <int L, int BGBIT, bool GUARD>
+__global__ __launch_bounds__(128 * L) void k_blind_rotate_wide1(DevKeys K, const double2* __restrict__ bkf1,
+                                                              const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                              int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
+                                                              unsigned* guard, const double2* __restrict__ gtw) {
+    constexpr int NW = 2 * L, NT = 64 * NW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* sT_all = reinterpret_cast<double2*>(smem);
+    double2* sTw = sT_all + NW * kTile;
+    int32_t* acc = reinterpret_cast<int32_t*>(sTw + kTwElems);
+    uint16_t* s_bara = reinterpret_cast<uint16_t*>(acc + 2 * kN);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;
+    const int64_t item = (int64_t)blockIdx.x;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    load_twiddles(sTw, gtw, tid, NT);
+    const LaneRoots R = make_roots(sTw, lane);
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+        for (int idx = tid; idx < 2 * kN / 4; idx += NT) dst[idx] = src[idx];
+        const uint16_t* bara = st_bara + (size_t)item * nb;
+        for (int idx = tid; idx < i1 - i0; idx += NT) s_bara[idx] = bara[i0 + idx];
+    }
+    __syncthreads();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;
+    const int pw = wave / L, qw = wave - pw * L;  // digit qw of polynomial pw = row `wave` of BK_i
+    const int sh = 32 - (qw + 1) * BGBIT;
+    const int32_t* accp = acc + pw * kN;
+    uint32_t* accu = reinterpret_cast<uint32_t*>(acc);
+    double dev_max = 0.0;
+
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readfirstlane((int32_t)s_bara[i - i0]);
+        if (a == 0) continue;  // workgroup-uniform
+        // BK_i rows [2L][2][8][64]: this wave's row, both output blocks, requested before anything else
+        const double2* __restrict__ bki = bkf1 + (size_t)i * (2 * L * 2 * kM) + (size_t)wave * (2 * kM) + lane;
+        double2 s0[8], s1[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            s0[k] = bki[k * 64];
+            s1[k] = bki[(8 + k) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int32_t lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // opaque: keeps 16 per-coefficient LDS addresses from being hoisted (and spilled)
+        uint32_t rv0[8], rv1[8], pv0[8], pv1[8];
+        const int32_t jb = (lane_o - a) & (2 * kN - 1);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int32_t j = 64 * r + lane_o;
+            rv0[r] = (uint32_t)accp[(jb + 64 * r) & (kN - 1)];
+            rv1[r] = (uint32_t)accp[(jb + 64 * r + kM) & (kN - 1)];
+            pv0[r] = (uint32_t)accp[j];
+            pv1[r] = (uint32_t)accp[j + kM];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t n0 = 0u - (((uint32_t)(jb + 64 * r) >> 10) & 1u);  // all ones where the rotation wrapped
+            const uint32_t n1 = 0u - (((uint32_t)(jb + 64 * r + kM) >> 10) & 1u);
+            const uint32_t u0 = ((rv0[r] ^ n0) - n0) - pv0[r] + dec_offset;
+            const uint32_t u1 = ((rv1[r] ^ n1) - n1) - pv1[r] + dec_offset;
+            const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)(u0 ^ (halfBg << sh)), sh, BGBIT);
+            const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
+            x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                          : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+        }
+        __syncthreads();  // A: every wave has read the accumulator; from here on it may be added to
+        fft512_forward<true, 1>(x, sT, lane, R);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double2 b0 = s0[k], b1 = s1[k];
+            s0[k] = cmulx<false>(x[k], b0);
+            s1[k] = cmulx<false>(x[k], b1);
+        }
+        fft512_inverse_pair<true>(s0, s1, sT, lane, R);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const double2 z0 = r == 0 ? make_double2(s0[0].x * (1.0 / 512.0), s0[0].y * (1.0 / 512.0)) : cmulx<true>(s0[r], untwist_reg(r));
+            const double2 z1 = r == 0 ? make_double2(s1[0].x * (1.0 / 512.0), s1[0].y * (1.0 / 512.0)) : cmulx<true>(s1[r], untwist_reg(r));
+            const double t00 = z0.x + kMagic, t01 = z0.y + kMagic, t10 = z1.x + kMagic, t11 = z1.y + kMagic;
+            if (GUARD) {
+                dev_max = fmax(dev_max, fmax(fabs(z0.x - (t00 - kMagic)), fabs(z0.y - (t01 - kMagic))));
+                dev_max = fmax(dev_max, fmax(fabs(z1.x - (t10 - kMagic)), fabs(z1.y - (t11 - kMagic))));
+            }
+            const int32_t j = 64 * r + lane;
+            atomicAdd(&accu[j], (uint32_t)__double2loint(t00));  // ds_add_u32: the 2L waves add their shares in any order
+            atomicAdd(&accu[j + kM], (uint32_t)__double2loint(t01));
+            atomicAdd(&accu[kN + j], (uint32_t)__double2loint(t10));
+            atomicAdd(&accu[kN + j + kM], (uint32_t)__double2loint(t11));
+        }
+        __syncthreads();  // B: accumulator complete before the next decomposition
+    }
+    if (GUARD) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
+        }
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = tid; j <= kN; j += NT)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+        for (int idx = tid; idx < 2 * kN / 4; idx += NT) dst[idx] = src[idx];
+    }
+}
+
 }  // namespace
 
 // N=1024, k=1 with either libtfhe parameter set: l=3/Bgbit=7 (>= v1.1, "128-bit") or l=2/Bgbit=10
@@ -1305,6 +1441,18 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         hipLaunchKernelGGL((k_blind_rotate_w1<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
                            st_acc, items, i0, i1, e, guard, gtw);                                                               \
     }
+    if (sub == 9 || sub == 10) {  // 2L waves per gate, every wave a whole row of the one-limb spectrum (latency); 10 = no guard arithmetic
+        static const bool attr_set =
+            hipFuncSetAttribute((const void*)k_blind_rotate_wide1<L, BGBIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+            hipFuncSetAttribute((const void*)k_blind_rotate_wide1<L, BGBIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide1");
+        const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
+        if (sub == 9)
+            hipLaunchKernelGGL((k_blind_rotate_wide1<L, BGBIT, true>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
+        else
+            hipLaunchKernelGGL((k_blind_rotate_wide1<L, BGBIT, false>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
+        return;
+    }
     if (sub == 7 || sub == 8) {  // two waves per gate on the one-limb spectrum (mid-size launches); 8 = without the guard arithmetic
         const dim3 g2((unsigned)items), b2(128);
         const size_t lds2 = (size_t)(2 * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
@@ -1339,7 +1487,7 @@ int32_t default_slice() {
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
-    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 8;
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 10;
     if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
@@ -1354,7 +1502,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
-    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1) ? nb : 64;
+    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || variant == kVariantWideOneLimb || variant == kVariantWideOneLimb + 1) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;

@@ -681,7 +681,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 1 && value <= 4096) {
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 21) {
+    } else if (name == "br_variant" && value >= 0 && value <= 23) {
         d_->br_variant = (int32_t)value;
     } else if (name == "exact_fft" && (value == 0 || value == 1)) {
         d_->exact_fft = value != 0;
@@ -691,6 +691,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->one_limb_min = value;
     } else if (name == "two_wave_max" && value >= 0) {
         d_->two_wave_max = value;
+
     } else if (name == "fft_guard_inject" && value == 1 && d_->fft_guard) {
         // test hook: the next call finds the guard tripped and repeats itself on the two-limb kernel
         const unsigned one = 1;
@@ -810,7 +811,7 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
         int32_t variant = d->br_variant, slice = d->br_slice;
         if (variant == 0) {
             if (cnt <= d->br_wide_max) {
-                variant = w64::kVariantWide;
+                variant = w64::kVariantWide;  // two limbs; its one-limb form (kVariantWideOneLimb) measured 15 % slower
                 slice = w64::bara_stride(p);
             } else if (!d->exact_fft && !d->exact_once && cnt >= d->one_limb_min) {
                 // while every gate fits a two-wave slot, two waves per gate finish a step sooner than one
