@@ -7,6 +7,8 @@ namespace ieache {
 namespace w64 {
 
 bool supported(const Params& p);
+// ... and the parameter sets whose sums leave the one-limb transform enough FP64 headroom (l=3, Bgbit=7)
+bool one_limb_supported(const Params& p);
 // number of double2 elements of the BK spectrum in this kernel's layout
 size_t spectrum_elems(const Params& p);
 size_t lds_bytes(const Params& p);

@@ -1327,6 +1327,11 @@ bool supported(const Params& p) {
     return p.N == kN && p.k == 1 && ((p.l == 3 && p.Bgbit == 7) || (p.l == 2 && p.Bgbit == 10)) && p.n <= 4096;
 }
 
+// The one-limb kernels round sums of up to 2l x N x 2^(Bgbit-1) x 2^31: 2^49.6 for l=3 / Bgbit=7, where the measured
+// rounding error is 35x below the guard's limit.  For l=2 / Bgbit=10 the worst case is 2^52 and the typical error 6.5x
+// larger -- inside 0.5 but no longer clear of the limit -- so that set stays on the two-limb kernels.
+bool one_limb_supported(const Params& p) { return supported(p) && p.l == 3 && p.Bgbit == 7; }
+
 size_t spectrum_elems(const Params& p) { return (size_t)p.n * p.kpl() * 4 * kM; }
 size_t spectrum1_elems(const Params& p) { return (size_t)p.n * p.kpl() * 2 * kM; }
 size_t lds_bytes_w1() { return (size_t)(kW1Gates * kTile + kTwElems) * sizeof(double2) + (size_t)kW1Gates * 2 * kN * 4; }

@@ -563,6 +563,7 @@ void Evaluator::init() {
         if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
         if (const char* e = getenv("IEACHE_ONE_LIMB_MIN")) d_->one_limb_min = atoll(e);
         if (const char* e = getenv("IEACHE_EXACT_FFT")) d_->exact_fft = atoi(e) != 0;
+        if (!w64::one_limb_supported(p)) d_->exact_fft = true;
         resident_two_wave_ = 4 * cus;
         if (d_->exact_fft) {
             resident_gates_ = 4 * cus;
@@ -683,7 +684,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_slice = (int32_t)value;
     } else if (name == "br_variant" && value >= 0 && value <= 23) {
         d_->br_variant = (int32_t)value;
-    } else if (name == "exact_fft" && (value == 0 || value == 1)) {
+    } else if (name == "exact_fft" && (value == 1 || (value == 0 && w64::one_limb_supported(p_)))) {
         d_->exact_fft = value != 0;
         resident_gates_ = (d_->exact_fft ? 4 : 8) * d_->cus;
         resident_two_wave_ = d_->exact_fft ? 0 : 4 * d_->cus;

@@ -883,6 +883,15 @@ def test_old_libtfhe_parameter_set_on_fast_kernel(ia, gpu_ctx):
         assert np.array_equal(kb.ck.gate("xor", a[i], b[i]), out[i]), i
     ctx.set_option("br_wide_max", 0)  # 16 gates took the 2L = 4 waves-per-gate kernel; now the two-wave one
     assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), out)
+    # this set's sums (4 x 1024 x 2^9 x 2^31 = 2^52) leave the one-limb transform too little FP64 headroom: the context
+    # stays on the two-limb kernels and says so; forced, the one-limb kernels still agree (or trip the guard and repeat)
+    assert ctx.kernel_variant == "w2x64-radix8-registers" and ctx.fft_guard() == (0.0, 0)
+    with pytest.raises(ia.IeacheError):
+        ctx.set_option("exact_fft", 0)
+    for variant in (13, 20):
+        ctx.set_option("br_variant", variant)
+        assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), out), variant
+    ctx.set_option("br_variant", 0)
     ctx.set_option("br_wide_max", 256)
     x = kb.enc([1, 0, 1], 63)
     acc = ctx.debug_blind_rotate(x, 3)
