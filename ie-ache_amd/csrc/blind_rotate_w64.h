@@ -56,6 +56,9 @@ constexpr int32_t kVariantOneLimbTwoWaves = 20;
 // 22 = 2L waves per gate, each wave one whole row of the one-limb spectrum (k_blind_rotate_wide1: the latency kernel's
 // one-limb form; any slice length up to n), 23 = the same without the guard arithmetic
 constexpr int32_t kVariantWideOneLimb = 22;
+// 24 = k_blind_rotate_wide itself on the one-limb spectrum (two output waves instead of four; the evaluator's choice for
+// launches of at most one gate per CU)
+constexpr int32_t kVariantWideHandoverOneLimb = 24;
 
 }  // namespace w64
 }  // namespace ieache

@@ -1009,11 +1009,15 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const do
 // Same arithmetic as k_blind_rotate_w2 up to the order of exact-after-rounding FP64 sums, so the
 // integers it produces are identical.
 // dynamic LDS: sT [2L][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32 | bara [i1-i0] u16
-template <int L, int BGBIT, bool DIAG>
+// LIMBS = 1: the same kernel on the one-limb spectrum [n][2L][2][8][64] -- waves 0 and 1 own the two output polynomials,
+// half the BK bytes and LDS reads per step, guarded rounding (`guard`, see k_blind_rotate_w1).
+template <int L, int BGBIT, bool DIAG, int LIMBS = 2>
 __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const double2* __restrict__ bkf,
                                                              const uint16_t* __restrict__ st_bara, int32_t nb,
                                                              int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
-                                                             unsigned long long* diag, const double2* __restrict__ gtw) {
+                                                             unsigned long long* diag, const double2* __restrict__ gtw,
+                                                             unsigned* guard) {
+    constexpr int RS = 2 * LIMBS * kM;  // double2 elements per BK row
     constexpr int NW = 2 * L, NT = 64 * NW;
     extern __shared__ __align__(16) unsigned char smem[];
     double2* sT_all = reinterpret_cast<double2*>(smem);
@@ -1044,9 +1048,10 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
     const int pw = wave / L, qw = wave - pw * L;  // forward role: digit qw of polynomial pw
     const int sh = 32 - (qw + 1) * BGBIT;
     const int32_t* accp = acc + pw * kN;
-    const bool is_out = wave < 4;                 // inverse role: output polynomial wave>>1, limb wave&1
-    uint32_t* acco = reinterpret_cast<uint32_t*>(acc) + (wave >> 1) * kN;
-    const int lsh = (wave & 1) * 16;
+    const bool is_out = wave < 2 * LIMBS;         // inverse role: output polynomial wave>>1, limb wave&1 (one limb: polynomial wave)
+    uint32_t* acco = reinterpret_cast<uint32_t*>(acc) + (LIMBS == 2 ? (wave >> 1) : wave) * kN;
+    const int lsh = LIMBS == 2 ? (wave & 1) * 16 : 0;
+    double dev_max = 0.0;
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
     if (DIAG) tlast = stamp();
 #define IEACHE_STAMP(idx)                      \
@@ -1065,13 +1070,13 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
         // step, so the loads are issued in three instalments spread over the step: rows 0,1 now (they
         // fly under the decomposition and the transform), rows 2,3 after the transform, rows 4,5 once
         // rows 0,1 are consumed.
-        const double2* __restrict__ bki = bkf + (size_t)i * (2 * L * 4 * kM) + (size_t)wave * kM + lane;
+        const double2* __restrict__ bki = bkf + (size_t)i * (2 * L * RS) + (size_t)wave * kM + lane;
         double2 bA[2][8], bB[2][8], s[8];
         if (is_out) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                bA[0][k] = bki[(size_t)0 * 4 * kM + k * 64];
-                bA[1][k] = bki[(size_t)1 * 4 * kM + k * 64];
+                bA[0][k] = bki[(size_t)0 * RS + k * 64];
+                bA[1][k] = bki[(size_t)1 * RS + k * 64];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1112,8 +1117,8 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
         if (is_out) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                bB[0][k] = bki[(size_t)2 * 4 * kM + k * 64];
-                bB[1][k] = bki[(size_t)3 * 4 * kM + k * 64];
+                bB[0][k] = bki[(size_t)2 * RS + k * 64];
+                bB[1][k] = bki[(size_t)3 * RS + k * 64];
             }
         }
         IEACHE_STAMP(2)
@@ -1135,8 +1140,8 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
             if (NW > 4) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    bA[0][k] = bki[(size_t)4 * 4 * kM + k * 64];
-                    bA[1][k] = bki[(size_t)5 * 4 * kM + k * 64];
+                    bA[0][k] = bki[(size_t)4 * RS + k * 64];
+                    bA[1][k] = bki[(size_t)5 * RS + k * 64];
                 }
             }
             IEACHE_MAC_ROW(2, bB[0])
@@ -1155,8 +1160,10 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
-                const uint32_t c0 = (uint32_t)__double2loint(z.x + kMagic) << lsh;
-                const uint32_t c1 = (uint32_t)__double2loint(z.y + kMagic) << lsh;
+                const double t0 = z.x + kMagic, t1 = z.y + kMagic;
+                if (LIMBS == 1) dev_max = fmax(dev_max, fmax(fabs(z.x - (t0 - kMagic)), fabs(z.y - (t1 - kMagic))));
+                const uint32_t c0 = (uint32_t)__double2loint(t0) << lsh;
+                const uint32_t c1 = (uint32_t)__double2loint(t1) << lsh;
                 const int32_t j = 64 * r + lane;
                 atomicAdd(&acco[j], c0);       // ds_add_u32; the partner limb adds its share to the same word
                 atomicAdd(&acco[j + kM], c1);
@@ -1167,6 +1174,16 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
         IEACHE_STAMP(7)
     }
 #undef IEACHE_STAMP
+    if (LIMBS == 1 && guard && is_out) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > 0.0625f) atomicAdd(&guard[0], 1u);
+        }
+    }
     if (DIAG && diag && lane == 0 && (wave == 0 || wave == 4)) {
 #pragma unroll
         for (int t = 0; t < 8; t++) atomicAdd(&diag[(wave >> 2) * 8 + t], tsum[t]);
@@ -1413,9 +1430,9 @@ static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream
         if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide");
         const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
         if (variant == kVariantWide)
-            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw);
+            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw, (unsigned*)nullptr);
         else
-            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, true>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw);
+            hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, true>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw, (unsigned*)nullptr);
         return;
     }
     switch (variant) {
@@ -1445,6 +1462,15 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_w1"); \
         hipLaunchKernelGGL((k_blind_rotate_w1<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
                            st_acc, items, i0, i1, e, guard, gtw);                                                               \
+    }
+    if (sub == 11) {  // the latency kernel (2L waves per gate, spectra handed to the output waves) on the one-limb spectrum
+        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, false, 1>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide<1 limb>");
+        const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
+        hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false, 1>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, d_bkf1, st_bara,
+                           nb, st_acc, i0, i1, e, (unsigned long long*)nullptr, gtw, guard);
+        return;
     }
     if (sub == 9 || sub == 10) {  // 2L waves per gate, every wave a whole row of the one-limb spectrum (latency); 10 = no guard arithmetic
         static const bool attr_set =
@@ -1492,7 +1518,7 @@ int32_t default_slice() {
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
-    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 10;
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 11;
     if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
@@ -1507,7 +1533,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
-    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || variant == kVariantWideOneLimb || variant == kVariantWideOneLimb + 1) ? nb : 64;
+    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || variant == kVariantWideOneLimb || variant == kVariantWideOneLimb + 1 || variant == kVariantWideOneLimb + 2) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;

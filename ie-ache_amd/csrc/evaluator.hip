@@ -682,7 +682,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 1 && value <= 4096) {
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 23) {
+    } else if (name == "br_variant" && value >= 0 && value <= 24) {
         d_->br_variant = (int32_t)value;
     } else if (name == "exact_fft" && (value == 1 || (value == 0 && w64::one_limb_supported(p_)))) {
         d_->exact_fft = value != 0;
@@ -812,7 +812,8 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
         int32_t variant = d->br_variant, slice = d->br_slice;
         if (variant == 0) {
             if (cnt <= d->br_wide_max) {
-                variant = w64::kVariantWide;  // two limbs; its one-limb form (kVariantWideOneLimb) measured 15 % slower
+                // the latency kernel, on the one-limb spectrum unless exactness by construction is asked for
+                variant = (d->exact_fft || d->exact_once) ? w64::kVariantWide : w64::kVariantWideHandoverOneLimb;
                 slice = w64::bara_stride(p);
             } else if (!d->exact_fft && !d->exact_once && cnt >= d->one_limb_min) {
                 // while every gate fits a two-wave slot, two waves per gate finish a step sooner than one
