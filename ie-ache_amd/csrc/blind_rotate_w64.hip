@@ -1011,7 +1011,8 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const do
 // dynamic LDS: sT [2L][kTile] double2 | tw [kTwElems] double2 | acc [2][1024] int32 | bara [i1-i0] u16
 // LIMBS = 1: the same kernel on the one-limb spectrum [n][2L][2][8][64] -- waves 0 and 1 own the two output polynomials,
 // half the BK bytes and LDS reads per step, guarded rounding (`guard`, see k_blind_rotate_w1).
-template <int L, int BGBIT, bool DIAG, int LIMBS = 2>
+// XF / XI: which transposes of the forward / inverse transform go cross-lane instead of through LDS (bit 0 lane-high, bit 1 lane-low)
+template <int L, int BGBIT, bool DIAG, int LIMBS = 2, int XF = 0, int XI = 0>
 __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const double2* __restrict__ bkf,
                                                              const uint16_t* __restrict__ st_bara, int32_t nb,
                                                              int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
@@ -1109,7 +1110,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
                           : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
         }
         IEACHE_STAMP(0)
-        fft512_forward<true>(x, sT, lane, R);
+        fft512_forward<true, XF>(x, sT, lane, R);
         IEACHE_STAMP(1)
 #pragma unroll
         for (int k = 0; k < 8; k++) sT[k * 64 + lane] = x[k];  // publish
@@ -1156,7 +1157,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
         __syncthreads();  // B: every spectrum has been consumed, tiles are scratch again
         IEACHE_STAMP(5)
         if (is_out) {
-            fft512_inverse<true>(s, sT, lane, R);
+            fft512_inverse<true, XI>(s, sT, lane, R);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
@@ -1463,13 +1464,24 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         hipLaunchKernelGGL((k_blind_rotate_w1<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
                            st_acc, items, i0, i1, e, guard, gtw);                                                               \
     }
-    if (sub == 11) {  // the latency kernel (2L waves per gate, spectra handed to the output waves) on the one-limb spectrum
-        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, false, 1>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide<1 limb>");
+    if (sub >= 11 && sub <= 15) {  // the latency kernel (2L waves per gate, spectra handed to the output waves) on the one-limb spectrum
         const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
-        hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false, 1>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, d_bkf1, st_bara,
-                           nb, st_acc, i0, i1, e, (unsigned long long*)nullptr, gtw, guard);
+#define IEACHE_WIDE1(XF, XI)                                                                                                       \
+    {                                                                                                                              \
+        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, false, 1, XF, XI>,             \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;    \
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide<1 limb>"); \
+        hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false, 1, XF, XI>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, \
+                           d_bkf1, st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr, gtw, guard);                      \
+    }
+        switch (sub) {  // transposes cross-lane instead of through LDS: forward / inverse, lane-high (1), both (3)
+            case 12: IEACHE_WIDE1(1, 0) break;
+            case 13: IEACHE_WIDE1(3, 0) break;
+            case 14: IEACHE_WIDE1(1, 1) break;
+            case 15: IEACHE_WIDE1(3, 3) break;
+            default: IEACHE_WIDE1(0, 0) break;
+        }
+#undef IEACHE_WIDE1
         return;
     }
     if (sub == 9 || sub == 10) {  // 2L waves per gate, every wave a whole row of the one-limb spectrum (latency); 10 = no guard arithmetic
@@ -1518,7 +1530,7 @@ int32_t default_slice() {
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
-    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 11;
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 15;
     if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
@@ -1533,7 +1545,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
-    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || variant == kVariantWideOneLimb || variant == kVariantWideOneLimb + 1 || variant == kVariantWideOneLimb + 2) ? nb : 64;
+    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || (variant >= kVariantWideOneLimb && variant <= kVariantWideOneLimb + 6)) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
