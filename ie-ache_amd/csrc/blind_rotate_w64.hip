@@ -1464,6 +1464,15 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         hipLaunchKernelGGL((k_blind_rotate_w1<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
                            st_acc, items, i0, i1, e, guard, gtw);                                                               \
     }
+    if (sub == 16) {  // ... with the s_memtime phase stamps (diagnostic)
+        const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
+        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, true, 1>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide<1 limb, diag>");
+        hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, true, 1>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, d_bkf1, st_bara,
+                           nb, st_acc, i0, i1, e, diag_buf(), gtw, guard);
+        return;
+    }
     if (sub >= 11 && sub <= 15) {  // the latency kernel (2L waves per gate, spectra handed to the output waves) on the one-limb spectrum
         const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
 #define IEACHE_WIDE1(XF, XI)                                                                                                       \
@@ -1530,7 +1539,7 @@ int32_t default_slice() {
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
-    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 15;
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 16;
     if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
@@ -1545,7 +1554,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
-    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || (variant >= kVariantWideOneLimb && variant <= kVariantWideOneLimb + 6)) ? nb : 64;
+    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || (variant >= kVariantWideOneLimb && variant <= kVariantWideOneLimb + 7)) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
@@ -1561,7 +1570,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
         else
             launch_slice<2, 10>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, d_twiddles);
     }
-    if (variant == 1 || variant == 4 || variant == kVariantWide + 1) diag_report(stream, items, nsteps, variant);
+    if (variant == 1 || variant == 4 || variant == kVariantWide + 1 || variant == kVariantWideOneLimb + 7) diag_report(stream, items, nsteps, variant == kVariantWideOneLimb + 7 ? kVariantWide + 1 : variant);
     if (nsteps == 0 && ext) {
         // degenerate (steps == 0): extraction straight from the initial accumulator
         if (p.l == 3)
