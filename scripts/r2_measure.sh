@@ -6,7 +6,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r2_meas
-mkdir -p $OUT
+rm -rf $OUT/stats $OUT/pmc; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_rocprof.json 2> $OUT/bench_rocprof.err
 echo "bench under rocprof done"; tail -c 600 $OUT/bench_rocprof.json
 find $OUT/stats -name "*kernel_stats.csv" | head -3
