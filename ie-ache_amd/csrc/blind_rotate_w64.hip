@@ -698,7 +698,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 // mantissa holds) and pays for it with a second inverse transform and a second set of row products per output
 // polynomial.  libtfhe itself multiplies with ONE double-precision transform of the 32-bit coefficients; the sums
 // then reach 2^49.6 in the worst case and ~2^43 on real data, where the transform's rounding error is ~2^-9 of an
-// integer step (measured max 0.007) -- far from the 0.5 that would change a rounded
+// integer step (largest seen in a whole bench run: 0.014) -- far from the 0.5 that would change a rounded
 // coefficient, but not provably so.  This kernel takes that form and WATCHES the error: every inverse-transformed
 // coefficient's distance to the nearest integer is folded into a running maximum, published per launch (guard[1],
 // float bits) and counted (guard[0]) when it exceeds kGuardLimit; the evaluator then repeats the call on the

@@ -840,6 +840,37 @@ def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
     ctx.set_option("br_wide_max", 256)
 
 
+def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
+    """The guarded one-limb kernels against the provably exact two-limb ones at n=630 on 16 384 gates per level, five levels
+    deep (each level's operands are the previous level's bootstrapped outputs): every sample identical, the guard silent
+    with its maximum far below the limit.  (GPU against GPU: the oracle takes 0.4 s per gate; it pins the two-limb kernels
+    in the tests above.)"""
+    z = np.load(os.path.join(G, "full_gate_kat.npz"))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(int(v) for v in z["seed"]))
+    rng = np.random.default_rng(630)
+    cnt = 16384
+    bits = rng.integers(0, 2, size=(2, cnt)).astype(np.uint8)
+    a, b = kb.enc(bits[0], 71), kb.enc(bits[1], 72)
+    results = {}
+    for exact in (1, 0):
+        ctx.set_option("exact_fft", exact)
+        x, y, plain_x, plain_y = a, b, bits[0], bits[1]
+        outs = []
+        for level, gate in enumerate((ia.GATE_XOR, ia.GATE_AND, ia.GATE_OR, ia.GATE_NAND, ia.GATE_XOR)):
+            o = ctx.gates(gate, x, y)
+            outs.append(o)
+            x, y = o, np.roll(x, 1, axis=0)                 # next level: this level's outputs against shifted operands
+        results[exact] = outs
+    for lvl, (e, f) in enumerate(zip(results[1], results[0])):
+        assert np.array_equal(e, f), lvl
+    dev, reruns = ctx.fft_guard()
+    assert 0 < dev < 1 / 32 and reruns == 0
+    assert np.array_equal(kb.dec(results[0][0]), bits[0] ^ bits[1])
+    # a mid-size launch (two waves per gate) and a narrow one (latency kernel) of the same gates
+    for n_g in (900, 200):
+        assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:n_g], b[:n_g]), results[1][0][:n_g]), n_g
+
+
 def test_full_config_add16_batch4096_decrypts(ia, gpu_ctx):
     """BASELINE.json configs[1] at full size (n=630, 4096 ciphertext pairs, 327 680 bootstraps): every one
     of the 4096 sums must decrypt to a+b mod 2^16 (the size-independent property), and a sampled
