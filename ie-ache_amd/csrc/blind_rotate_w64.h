@@ -34,30 +34,30 @@ int gates_per_workgroup_w1();
 // the kernels' twiddle table (twiddle_table_elems() double2 in device memory), built once per context
 size_t twiddle_table_elems();
 void build_twiddle_table(double2* d_tw, hipStream_t stream);
-// kernel variant: 0 = default (IEACHE_BR_VARIANT overrides): wave-local sync, the forward transforms' lane-high transpose
-// cross-lane (v_permlane*_swap / DPP), every other transpose -- and the paired inverse -- through LDS (+0.8 % over all-LDS,
-// which is variant 12); 1 = all-LDS with
-// s_memtime diagnostics printed to stderr; 2 = LDS transposes with workgroup barriers; 3 = cross-lane
-// (DPP / v_permlane*_swap) transposes; 4 = 3 with diagnostics; 5 / 6 = only the lane-high / lane-low transpose cross-lane;
-// 10 = forward-transform LDS stores interleaved with the twiddle multiplies that feed them (measured: no gain);
-// 11 = with round 1's (unneeded) workgroup barrier at the end of every CMux step.
-// All produce identical bits.
+// Kernel variants ("br_variant" / IEACHE_BR_VARIANT; all produce identical bits).  0 lets the EVALUATOR choose by launch
+// size (evaluator.hip: <= one gate per CU -> 24, <= 4 per CU -> 20, above -> 13; "exact_fft": 7 / 0); passed to launch()
+// itself, 0 is the two-limb two-wave kernel.
+//   two limbs (exact by construction), two waves per gate -- k_blind_rotate_w2:
+//     0  wave-local sync, the forward transforms' lane-high transpose cross-lane (v_permlane*_swap / DPP), every other
+//        transpose and the paired inverse through LDS       12  every transpose through LDS (round 1's default)
+//     1  12 with s_memtime phase stamps on stderr            2  LDS transposes with workgroup barriers
+//     3  every transpose cross-lane   4  3 with stamps       5 / 6  only the lane-high / lane-low transposes cross-lane
+//     10 forward-transform LDS stores interleaved with the twiddle multiplies that feed them (no gain)
+//     11 with round 1's (unneeded) workgroup barrier at the end of every CMux step
+//   two limbs, 2L waves per gate -- k_blind_rotate_wide (latency; any slice length up to n):   7   (8 with stamps)
+//   one limb with the rounding guard, one wave per gate -- k_blind_rotate_w1 (wide launches):
+//     13 default   14 without the guard arithmetic   15 / 16 forward transposes both through LDS / both cross-lane
+//     17 / 18 / 19 second BK block of a row requested before its transform / after its first / second twiddles
+//   one limb, two waves per gate -- k_blind_rotate_w2s (mid-size launches):   20   (21 without the guard arithmetic)
+//   one limb, 2L waves per gate (latency):
+//     22 / 23 every wave a whole row, no hand-over -- k_blind_rotate_wide1 (measured slower; 23 without guard arithmetic)
+//     24 k_blind_rotate_wide on the one-limb spectrum (narrow launches)   25-28 its transposes cross-lane (slower)
+//     29 24 with phase stamps
 int32_t default_variant();
-// 7 = 2L waves per gate (k_blind_rotate_wide): lower latency per gate, for launches of few gates;
-// takes any slice length up to n (one launch for the whole rotation)
 constexpr int32_t kVariantWide = 7;
-// 13 = one wave per gate on the one-limb spectrum with the rounding guard (k_blind_rotate_w1; the evaluator's default for
-// wide launches), 14 = the same without the guard arithmetic (measurement only).  Bit-identical to the two-limb kernels
-// as long as the guard stays silent.
 constexpr int32_t kVariantOneLimb = 13;
-// 20 = two waves per gate on the one-limb spectrum (k_blind_rotate_w2s; the evaluator's choice for mid-size launches),
-// 21 = the same without the guard arithmetic
 constexpr int32_t kVariantOneLimbTwoWaves = 20;
-// 22 = 2L waves per gate, each wave one whole row of the one-limb spectrum (k_blind_rotate_wide1: the latency kernel's
-// one-limb form; any slice length up to n), 23 = the same without the guard arithmetic
 constexpr int32_t kVariantWideOneLimb = 22;
-// 24 = k_blind_rotate_wide itself on the one-limb spectrum (two output waves instead of four; the evaluator's choice for
-// launches of at most one gate per CU)
 constexpr int32_t kVariantWideHandoverOneLimb = 24;
 
 }  // namespace w64
