@@ -78,7 +78,7 @@ public:
     // Maximum gate instances per launch (bounds the scratch buffers).
     void set_chunk(size_t items);
     // Named tuning knobs: "chunk", "force_generic", "ks_sliced_min" (gate instances per launch from which
-    // the hand-scheduled key switch is used; default 768), "ks_gates" (its gate instances per workgroup:
+    // the hand-scheduled key switch is used; default 576), "ks_gates" (its gate instances per workgroup:
     // 4, 8, 16, 32, or 0 = by launch size), "ks_slice" (coefficients per launch of it, 0 = whole walk),
     // "ks_batch_min" (same threshold for the compiler-scheduled gate-batched kernel, the cross-check),
     // "br_slice" (CMux steps per blind-rotation launch, 1..64),

@@ -521,7 +521,7 @@ struct Evaluator::Impl {
     bool ks_batch_ok = false;     // gate-batched key switch usable (base == 4, digits fit 16 bits, columns fit 8 waves)
     int64_t ks_batch_min = 4096;  // use it from this many gate instances per launch (one workgroup walk takes ~5 ms)
     bool ks_sliced_ok = false;    // hand-scheduled sliced variant of it usable (t = 8, basebit = 2)
-    int64_t ks_sliced_min = 768;  // ... and used from this many gate instances per launch
+    int64_t ks_sliced_min = 576;  // ... and used from this many gate instances per launch (measured crossover with the per-gate kernel: ~560)
     int32_t ks_slice = 0;         // coefficients per launch of the sliced key switch; 0 = the whole walk
     int32_t ks_gates = 0;         // gate instances per workgroup there (8 / 16 / 32); 0 = by launch size
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default

@@ -626,7 +626,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     rng = np.random.default_rng(3)
     bits = rng.integers(0, 2, size=(2, 2304)).astype(np.uint8)
     a, b = kb.enc(bits[0], 41), kb.enc(bits[1], 42)
-    ref = ctx.gates(ia.GATE_AND, a, b)                     # defaults: slice 16, sliced key switch (>= 768 gates)
+    ref = ctx.gates(ia.GATE_AND, a, b)                     # defaults: slice 16, sliced key switch (>= 576 gates)
     assert np.array_equal(kb.dec(ref), bits[0] & bits[1])
     for i in (0, 1, 2303):
         assert np.array_equal(kb.ck.gate("and", a[i], b[i]), ref[i])
@@ -678,7 +678,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     ctx.set_option("br_wide_max", 1 << 20)
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
     ctx.set_option("br_wide_max", 256)
-    # key switch: the defaults above took the sliced hand-scheduled kernel (>= 768 gates); now every other one
+    # key switch: the defaults above took the sliced hand-scheduled kernel (>= 576 gates); now every other one
     ctx.set_option("ks_sliced_min", 1 << 40)
     ctx.set_option("ks_batch_min", 1 << 40)                # per-gate vectorised key switch
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
@@ -693,7 +693,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:cnt], b[:cnt]), ref[:cnt]), (gates, sl, cnt)
     ctx.set_option("ks_gates", 0)
     ctx.set_option("ks_slice", 0)
-    ctx.set_option("ks_sliced_min", 768)
+    ctx.set_option("ks_sliced_min", 576)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("ks_gates", 12)
     ctx.force_generic(True)
