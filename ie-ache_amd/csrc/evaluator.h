@@ -81,6 +81,8 @@ public:
     // the hand-scheduled key switch is used; default 576), "ks_gates" (its gate instances per workgroup:
     // 4, 8, 16, 32, or 0 = by launch size), "ks_slice" (coefficients per launch of it, 0 = whole walk),
     // "ks_batch_min" (same threshold for the compiler-scheduled gate-batched kernel, the cross-check),
+    // "ks_split_max" (workgroups the per-gate key switch may cut one gate's walk into when a launch holds only a
+    // handful of gates; default 16, 1 = never),
     // "br_slice" (CMux steps per blind-rotation launch, 1..64),
     // "br_wide_max" (launches of at most this many gate instances use the latency-oriented
     // 2L-waves-per-gate kernel; default = the device's CU count, 0 = never), "br_variant",

@@ -268,7 +268,10 @@ __global__ __launch_bounds__(kThreads) void k_keyswitch_generic(DevKeys K, WorkD
 constexpr int kKsThreads = 512;
 template <int NLD>
 __global__ __launch_bounds__(kKsThreads) void k_keyswitch_vec(DevKeys K, WorkDesc W, const Torus32* ext,
-                                                              Torus32* flat_out) {
+                                                              Torus32* flat_out, int32_t splits) {
+    // splits > 1 (launches of a handful of gates, where one workgroup per gate leaves the chip idle and the walk's
+    // latency is what counts): blockIdx.y takes coefficients [y*N/splits, (y+1)*N/splits) and ADDS its share to an
+    // output row that k_keyswitch_init has set to (0, ..., 0, b); int32 addition commutes, so the bits do not change
     extern __shared__ __align__(16) unsigned char smem[];
     const int32_t N = K.N, n = K.n, t = K.ks_t, basebit = K.ks_basebit, stride = K.stride;
     int32_t* u = reinterpret_cast<int32_t*>(smem);
@@ -283,7 +286,9 @@ __global__ __launch_bounds__(kKsThreads) void k_keyswitch_vec(DevKeys K, WorkDes
     __syncthreads();
     const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
     const uint32_t mask = (1u << basebit) - 1;
-    for (int32_t idx = tid; idx < N * t; idx += kKsThreads) {
+    const int32_t idx0 = splits > 1 ? (int32_t)blockIdx.y * (N / splits) * t : 0;
+    const int32_t idx1 = splits > 1 ? idx0 + (N / splits) * t : N * t;
+    for (int32_t idx = idx0 + tid; idx < idx1; idx += kKsThreads) {
         const int32_t i = idx / t, j = idx - i * t;
         const uint32_t d = (((uint32_t)u[i] + prec_offset) >> (32 - (j + 1) * basebit)) & mask;
         if (d) list[atomicAdd(&s_count, 1u)] = ((uint32_t)idx << basebit) + d;  // row index [i][j][d]
@@ -337,9 +342,22 @@ __global__ __launch_bounds__(kKsThreads) void k_keyswitch_vec(DevKeys K, WorkDes
         uint32_t v = 0;
 #pragma unroll
         for (int w = 0; w < 8; w++) v += (uint32_t)parti[(size_t)w * stride + q];
+        if (splits > 1) {
+            if (q <= n) atomicAdd(reinterpret_cast<uint32_t*>(out) + q, v);
+            continue;
+        }
         if (q == n) v += (uint32_t)u[N];
         out[q] = q <= n ? (int32_t)v : 0;
     }
+}
+
+// output rows of a split key switch: (0, ..., 0, b) with b the extracted sample's last word
+__global__ __launch_bounds__(256) void k_keyswitch_init(DevKeys K, WorkDesc W, const Torus32* ext, Torus32* flat_out) {
+    const int64_t item = (int64_t)blockIdx.x;
+    const int32_t n = K.n, stride = K.stride;
+    Torus32* out = flat_out ? flat_out + (size_t)item * stride : resolve(W, W.item0 + item, stride).out;
+    const Torus32 b = ext[(size_t)item * (K.N + 4) + K.N];
+    for (int32_t q = threadIdx.x; q < stride; q += 256) out[q] = q == n ? b : 0;
 }
 
 // ---- K5, gate-batched: one workgroup per G gate instances ----
@@ -524,6 +542,7 @@ struct Evaluator::Impl {
     int64_t ks_sliced_min = 576;  // ... and used from this many gate instances per launch (measured crossover with the per-gate kernel: ~560)
     int32_t ks_slice = 0;         // coefficients per launch of the sliced key switch; 0 = the whole walk
     int32_t ks_gates = 0;         // gate instances per workgroup there (8 / 16 / 32); 0 = by launch size
+    int32_t ks_split_max = 16;    // per-gate key switch: workgroups one gate's walk may be cut into when the launch is tiny
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
     int32_t br_variant = w64::default_variant();
     // launches of at most this many gate instances (one per CU) use the 2L-waves-per-gate kernel in a
@@ -678,6 +697,8 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->ks_slice = (int32_t)value;
     } else if (name == "ks_gates" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32)) {
         d_->ks_gates = (int32_t)value;
+    } else if (name == "ks_split_max" && value >= 1 && value <= 64) {
+        d_->ks_split_max = (int32_t)value;
     } else if (name == "br_wide_max" && value >= 0) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 1 && value <= 4096) {
@@ -847,11 +868,19 @@ static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkD
                            flat_out, cnt);
         return;
     }
+    // a handful of gates: cut each gate's walk into `splits` workgroups
+    int32_t splits = 1;
+    if (nld > 0 && d->ks_split_max > 1) {
+        // measured: pays while gates x splits stays within ~1.5 workgroups per CU (1-8 gates: 0.18 -> 0.03 ms, 44: 0.09, 256: no gain)
+        while (splits < d->ks_split_max && cnt * splits * 2 <= (3 * (int64_t)d->cus) / 2 && K.N % (splits * 2) == 0) splits *= 2;
+    }
+    dim3 vgrid((unsigned)cnt, (unsigned)splits);
+    if (splits > 1) hipLaunchKernelGGL(k_keyswitch_init, grid, dim3(256), 0, stream, K, w, ext, flat_out);
     switch (nld) {
-        case 1: hipLaunchKernelGGL(k_keyswitch_vec<1>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
-        case 2: hipLaunchKernelGGL(k_keyswitch_vec<2>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
-        case 3: hipLaunchKernelGGL(k_keyswitch_vec<3>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
-        case 4: hipLaunchKernelGGL(k_keyswitch_vec<4>, grid, blk, d->ksv_lds, stream, K, w, ext, flat_out); break;
+        case 1: hipLaunchKernelGGL(k_keyswitch_vec<1>, vgrid, blk, d->ksv_lds, stream, K, w, ext, flat_out, splits); break;
+        case 2: hipLaunchKernelGGL(k_keyswitch_vec<2>, vgrid, blk, d->ksv_lds, stream, K, w, ext, flat_out, splits); break;
+        case 3: hipLaunchKernelGGL(k_keyswitch_vec<3>, vgrid, blk, d->ksv_lds, stream, K, w, ext, flat_out, splits); break;
+        case 4: hipLaunchKernelGGL(k_keyswitch_vec<4>, vgrid, blk, d->ksv_lds, stream, K, w, ext, flat_out, splits); break;
         default:
             hipLaunchKernelGGL(k_keyswitch_generic, grid, dim3(kThreads), d->ks_lds, stream, K, w, ext, flat_out);
     }

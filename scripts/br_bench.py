@@ -7,7 +7,7 @@ from ieache_amd import tools
 p = ia.default_params()
 k = tools.keygen_raw(p, (1, 2, 3))
 ctx = ia.Context.from_arrays(p, k["bk"], k["ksk"])
-for opt in ("br_variant", "br_slice", "exact_fft", "one_limb_min", "br_wide_max", "ks_batch_min", "ks_sliced_min", "ks_slice", "ks_gates"):  # e.g. BR_VARIANT=7 BR_SLICE=630
+for opt in ("br_variant", "br_slice", "exact_fft", "one_limb_min", "br_wide_max", "ks_split_max", "two_wave_max", "ks_batch_min", "ks_sliced_min", "ks_slice", "ks_gates"):  # e.g. BR_VARIANT=7 BR_SLICE=630
     if os.environ.get(opt.upper()):
         ctx.set_option(opt, int(os.environ[opt.upper()]))
 rng = np.random.default_rng(0)

@@ -682,6 +682,11 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     ctx.set_option("ks_sliced_min", 1 << 40)
     ctx.set_option("ks_batch_min", 1 << 40)                # per-gate vectorised key switch
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
+    for splits in (1, 2, 16, 64):                          # per-gate kernel with a gate's walk cut into several workgroups
+        ctx.set_option("ks_split_max", splits)             # (tiny launches; partial sums meet through atomic adds)
+        for cnt in (1, 5, 37, 200):
+            assert np.array_equal(ctx.gates(ia.GATE_AND, a[:cnt], b[:cnt]), ref[:cnt]), (splits, cnt)
+    ctx.set_option("ks_split_max", 16)
     ctx.set_option("ks_batch_min", 1)                      # gate-batched key switch even for tiny launches
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:37], b[:37]), ref[:37])  # ragged last group of 16
     ctx.set_option("ks_batch_min", 4096)
