@@ -509,6 +509,28 @@ __global__ __launch_bounds__(128) void k_br_prologue(DevKeys K, WorkDesc W, uint
     }
 }
 
+// One 8-register block [8][64] double2 of the BK spectrum through the buffer path: resource and byte offset in SGPRs,
+// the lane's 16 bytes as the only vector operand, the register index as the instruction's immediate (0-3 KiB) -- no
+// per-load 64-bit vector address arithmetic (global_load needs ~12 v_add_co / v_addc per row of two blocks).
+// Measured: +2.7 % for k_blind_rotate_w1 (vector-issue bound; br_variant 30 = the same kernel with global_load), neutral
+// for k_blind_rotate_w2s and -9 % for the two-limb k_blind_rotate_w2, which therefore keep global_load.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+template <bool BUF = true>
+__device__ __forceinline__ void load_bk_block(double2 (&dst)[8], __amdgpu_buffer_rsrc_t rsrc, int lane16, int soff,
+                                              const double2* __restrict__ base = nullptr) {
+    if (!BUF) {  // the same block with per-lane 64-bit addresses (global_load_dwordx4): the A/B partner of the measurement
+        const double2* p = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + soff + lane16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k] = p[k * 64];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const v4i_t d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16 + (k & 3) * 1024, soff + (k >> 2) * 4096, 0);
+        dst[k] = make_double2(__hiloint2double(d.y, d.x), __hiloint2double(d.w, d.z));
+    }
+}
+
 // ---- K3 (+K4): CMux steps [i0, i1) for every gate instance of the launch ----
 // One 128-thread workgroup (two waves) per gate instance.  The step index is the
 // OUTER loop of the evaluator: a chunk of gates is advanced S steps per launch, so
@@ -709,7 +731,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
 // dynamic LDS: sT [4][kTile] double2 | tw [kTwElems] double2 | acc [4][2][1024] int32     (78 848 B -> 2 per CU)
 constexpr int kW1Gates = 4;
 constexpr float kGuardLimit = 0.0625f;
-template <int L, int BGBIT, bool GUARD, int XLANE = 1, int EARLYB = 0>
+template <int L, int BGBIT, bool GUARD, int XLANE = 1, int EARLYB = 0, bool BUF = true>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K, const double2* __restrict__ bkf1,
                                                                       const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                       int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -744,6 +766,10 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
     constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
     double dev_max = 0.0;
+    constexpr int kRowBytes = 2 * kM * (int)sizeof(double2), kStepBytes = 2 * L * kRowBytes;
+    const __amdgpu_buffer_rsrc_t bk_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(bkf1), (short)0, K.n * kStepBytes, 0x00020000);  // raw dwords, bounds = the whole spectrum
+    const int lane16 = lane * (int)sizeof(double2);
 
     const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
 #pragma unroll 1
@@ -751,7 +777,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
         const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
         if (a == 0) continue;  // wave-uniform; exact arithmetic makes the step a no-op
         // BK_i rows [2L][2][8][64]
-        const double2* __restrict__ bki = bkf1 + (size_t)i * (2 * L * 2 * kM) + lane;
+        const int bki = i * kStepBytes;  // byte offset of BK_i, rows [2L][2][8][64] double2
         double2 s[2][8];
         uint32_t v0[8], v1[8];
         auto decompose = [&](const int32_t* accp) {
@@ -762,11 +788,10 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
                 v1[r] = (((uint32_t)rot_coef(accp, j + kM, a, kN) - (uint32_t)accp[j + kM]) + dec_offset) ^ dec_offset;
             }
         };
-        auto digit_row = [&](const int sh, const double2* __restrict__ brow, auto first) {
+        auto digit_row = [&](const int sh, const int brow, auto first) {
             constexpr bool FIRST = decltype(first)::value;  // the first row's products initialise s
             double2 x[8], bA[8], bB[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) bA[k] = brow[k * 64];         // -> output polynomial 0
+            load_bk_block<BUF>(bA, bk_rsrc, lane16, brow, bkf1);                  // -> output polynomial 0
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
@@ -775,24 +800,21 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
                               : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
             if (EARLYB == 1) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) bB[k] = brow[(8 + k) * 64];
+                load_bk_block<BUF>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (EARLYB >= 2) {
                 // the second block is requested inside the transform, into the registers its twiddles leave
                 // (2: after the first inter-pass twiddles, 3: after the second)
                 auto req = [&]() {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) bB[k] = brow[(8 + k) * 64];
+                    load_bk_block<BUF>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
                 };
                 fft512_forward<true, XLANE, 0, decltype(req), EARLYB == 3>(x, sT, lane, R, req);
             } else {
                 fft512_forward<true, XLANE, 0>(x, sT, lane, R);
             }
             if (EARLYB == 0) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) bB[k] = brow[(8 + k) * 64];   // -> output polynomial 1
+                load_bk_block<BUF>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);  // -> output polynomial 1
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -812,7 +834,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
         for (int row = 1; row < 2 * L; row++) {
             if (row == L) decompose(acc + kN);
             const int q = row >= L ? row - L : row;
-            digit_row(32 - (q + 1) * BGBIT, bki + (size_t)row * (2 * kM), std::false_type{});
+            digit_row(32 - (q + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
         }
         fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
         // back to coefficients: s[c] holds output polynomial c; round and accumulate
@@ -900,6 +922,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const do
     constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
     int32_t* accw = acc + wave * kN;  // the polynomial this wave decomposes and updates
     double dev_max = 0.0;
+
 
     const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
 #pragma unroll 1
@@ -1521,6 +1544,7 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         case 4: IEACHE_W1(true, 1, 1) break;     // both BK blocks of a row requested before its transform
         case 5: IEACHE_W1(true, 1, 2) break;     // the second one from inside the transform
         case 6: IEACHE_W1(true, 1, 3) break;
+        case 17: IEACHE_W1(true, 1, 0, false) break;  // BK blocks through global_load instead of buffer_load
         default: IEACHE_W1(true) break;
     }
 #undef IEACHE_W1
@@ -1539,7 +1563,7 @@ int32_t default_slice() {
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
-    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 16;
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 17;
     if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);

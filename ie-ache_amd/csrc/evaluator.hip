@@ -703,7 +703,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 1 && value <= 4096) {
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 29) {
+    } else if (name == "br_variant" && value >= 0 && value <= 30) {
         d_->br_variant = (int32_t)value;
     } else if (name == "exact_fft" && (value == 1 || (value == 0 && w64::one_limb_supported(p_)))) {
         d_->exact_fft = value != 0;

@@ -8,14 +8,14 @@ p = ia.default_params()
 k = tools.keygen_raw(p, (1, 2, 3))
 ctx = ia.Context.from_arrays(p, k["bk"], k["ksk"])
 rng = np.random.default_rng(5)
-count = 2500
+count = 8192
 bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
 a = tools.encrypt_bits(p, k["lwe_key"], bits[0], 11)
 b = tools.encrypt_bits(p, k["lwe_key"], bits[1], 12)
 ctx.set_option("exact_fft", 1)
 ref = ctx.gates(ia.GATE_XOR, a, b)
 ctx.set_option("exact_fft", 0)
-for variant, counts in ((30, (1, 37, 256, 300)), (24, (1, 37, 256))):
+for variant, counts in ((20, (600, 1024)), (13, (4099,))):
     ctx.set_option("br_variant", variant)
     for c in counts:
         best = None

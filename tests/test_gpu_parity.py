@@ -644,7 +644,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     ctx.set_option("br_slice", 16)
     # one wave per gate on the one-limb spectrum (the default for wide launches, which `ref` above took): with and without
     # the guard arithmetic, forward transposes through LDS / cross-lane, early BK requests; ragged last workgroup of 4 gates
-    for variant in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28):  # 20 / 21: two waves per gate on the one-limb spectrum; 22 / 23: 2L waves, a row each; 24-28: the latency kernel on one limb (transposes through LDS / cross-lane)
+    for variant in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30):  # 20 / 21: two waves per gate on the one-limb spectrum; 22 / 23: 2L waves, a row each; 24-28: the latency kernel on one limb (transposes through LDS / cross-lane)
         ctx.set_option("br_variant", variant)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), variant
     ctx.set_option("br_variant", 13)
@@ -706,7 +706,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
     ctx.force_generic(False)
     with pytest.raises(ia.IeacheError):
-        ctx.set_option("br_variant", 30)
+        ctx.set_option("br_variant", 31)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("br_slice", 4097)
     with pytest.raises(ia.IeacheError):
