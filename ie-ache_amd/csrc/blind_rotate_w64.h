@@ -48,6 +48,7 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //   one limb with the rounding guard, one wave per gate -- k_blind_rotate_w1 (wide launches):
 //     13 default   14 without the guard arithmetic   15 / 16 forward transposes both through LDS / both cross-lane
 //     17 / 18 / 19 second BK block of a row requested before its transform / after its first / second twiddles
+//     30 BK blocks through global_load instead of buffer_load (-2.7 %)
 //   one limb, two waves per gate -- k_blind_rotate_w2s (mid-size launches):   20   (21 without the guard arithmetic)
 //   one limb, 2L waves per gate (latency):
 //     22 / 23 every wave a whole row, no hand-over -- k_blind_rotate_wide1 (measured slower; 23 without guard arithmetic)
