@@ -513,7 +513,8 @@ __global__ __launch_bounds__(128) void k_br_prologue(DevKeys K, WorkDesc W, uint
 // the lane's 16 bytes as the only vector operand, the register index as the instruction's immediate (0-3 KiB) -- no
 // per-load 64-bit vector address arithmetic (global_load needs ~12 v_add_co / v_addc per row of two blocks).
 // Measured: +2.7 % for k_blind_rotate_w1 (vector-issue bound; br_variant 30 = the same kernel with global_load), neutral
-// for k_blind_rotate_w2s and -9 % for the two-limb k_blind_rotate_w2, which therefore keep global_load.
+// for k_blind_rotate_w2s, -9 % for the two-limb k_blind_rotate_w2 and -13 % for the latency kernel (2.78 -> 3.20 ms), which
+// therefore keep global_load.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 template <bool BUF = true>
 __device__ __forceinline__ void load_bk_block(double2 (&dst)[8], __amdgpu_buffer_rsrc_t rsrc, int lane16, int soff,
