@@ -113,12 +113,19 @@ const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits, size_t batch = 0
         return &ctx->circuits.emplace(key, std::move(c)).first->second;
     };
     const Circuit* base = fetch(0);
-    if (!base || !base->balanced_schedule || !ctx->level_quantum) return base;
-    // slack-balanced circuits: level width chosen so that a level x this batch is a whole number of the
-    // workgroup rounds the GPU holds at once (same DAG, same output bits, another level assignment)
+    if (const char* e = getenv("IEACHE_LEVEL_CAP")) {  // measurement aid: force a level width (and with it the balanced schedule)
+        const int forced = atoi(e);
+        if (base && forced > 0) return fetch(forced);
+    }
+    if (!base || !ctx->level_quantum) return base;
+    // level width chosen so that a level x this batch is a whole number of the rounds of gates the GPU holds at once
+    // (same DAG, same output bits, another level assignment): the slack-balanced 64/128-bit multipliers at any batch
+    // below a round, the ASAP-scheduled 32-bit multiplier family at small batches (circuit_level_cap)
     const int cap = circuit_level_cap(*base, (int64_t)batch, ctx->eval->resident_gates(), ctx->eval->resident_gates_two_wave());
     const int mean = (int)((base->n_bootstraps + base->depth - 1) / base->depth);
-    return cap > 0 && cap != mean ? fetch(cap) : base;
+    if (cap <= 0 || (base->balanced_schedule && cap == mean)) return base;
+    const Circuit* capped = fetch(cap);
+    return capped && capped->balanced_schedule ? capped : base;
 }
 // the context is owned by a unique_ptr until it is handed to the caller, so a throwing key load
 // (or Evaluator constructor) releases it

@@ -609,7 +609,9 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool
     // schedule is used where it pays in memory: the 64/128-bit multipliers, whose ASAP wire store
     // is 2.7-5.8x larger (mul128: 16 800 vs 2 921 rows of 2.5 KB per expression).
     static const char* force = getenv("IEACHE_SCHEDULE");  // "asap" | "balanced": A/B switch for measurements
-    bool use_balanced = balanced && has_mul && sched_bits >= 64;
+    // ... and wherever the caller asks for a level width (level_cap > 0: small batches of the 32-bit multiplier, whose ASAP
+    // levels swing between a fraction of a round of resident workgroups and several)
+    bool use_balanced = balanced && has_mul && (sched_bits >= 64 || level_cap > 0);
     if (force && std::string(force) == "asap") use_balanced = false;
     if (force && std::string(force) == "balanced") use_balanced = balanced;
     *out = finalize_circuit(name + std::to_string(bits) + (fold ? "_folded" : ""), b, result, use_balanced, use_balanced ? level_cap : 0);
@@ -622,7 +624,25 @@ bool build_circuit(int32_t kind, int32_t bits, Circuit* out, bool balanced, bool
     return true;
 }
 
+// ASAP-scheduled wide circuits (the 32-bit multiplier and what is built on it) at small batches: their levels swing
+// between a fraction of a round of resident gates and several (mul32: 1 ... 70 gates per expression around a mean of 44), so a
+// level x batch is rarely a whole number of rounds.  Re-levelled with the slack-balanced scheduler to floor(m x resident /
+// batch) gates per expression, m = the whole number of rounds nearest the mean level, every launch is m (almost) full rounds:
+// measured +12.6 % at a batch of 58 (level width 35), +10 % at 64 (32), +8 % at 100 (40 = two rounds), +3 % at 128 (48 = three),
+// nothing from 200 on.
+static int32_t round_level_cap(const Circuit& base, int64_t batch, int32_t resident) {
+    if (batch <= 0 || resident <= 0 || base.depth <= 0) return 0;
+    const int64_t mean = (base.n_bootstraps + base.depth - 1) / base.depth;
+    if (mean < 8 || base.depth < 128) return 0;  // adders have nothing to balance; the shallow carry-save trees are all critical path
+    const int64_t m = (2 * mean * batch + resident) / (2 * (int64_t)resident);  // rounds per mean level, to nearest
+    if (m < 1 || m > 3) return 0;
+    const int64_t cap = m * resident / batch;
+    if (cap * 10 < mean * 6) return 0;  // far below the mean: too many levels
+    return (int32_t)cap;
+}
+
 int32_t circuit_level_cap(const Circuit& base, int64_t batch, int32_t resident, int32_t resident_alt) {
+    if (!base.balanced_schedule) return round_level_cap(base, batch, resident);
     // resident_alt: a second, smaller residency the evaluator also runs efficiently (the two-waves-per-gate kernel's 4 per
     // CU below the one-wave kernel's 8 per CU): tried when the batch is too small to fill levels of the first
     if (resident_alt > 0) {

@@ -277,7 +277,7 @@ void cloud_eval_jobs(Evaluator& eval, const std::vector<CloudJob*>& jobs, std::v
     if (!build_circuit(first.kind, first.int_bit, &base, true, first.fold)) throw std::invalid_argument("unsupported circuit");
     const Circuit* circ = &base;
     const int32_t cap = circuit_level_cap(base, (int64_t)jobs.size(), eval.resident_gates(), eval.resident_gates_two_wave());
-    if (cap > 0 && build_circuit(first.kind, first.int_bit, &capped, true, first.fold, cap)) circ = &capped;
+    if (cap > 0 && build_circuit(first.kind, first.int_bit, &capped, true, first.fold, cap) && capped.balanced_schedule) circ = &capped;
     const size_t S = (size_t)first.params.n + 1, n_in = (size_t)circ->n_inputs * S, n_out = circ->outputs.size() * S;
     std::vector<Torus32> in(jobs.size() * n_in), out(jobs.size() * n_out);
     for (size_t i = 0; i < jobs.size(); i++) {

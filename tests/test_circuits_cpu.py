@@ -207,7 +207,18 @@ def test_batch_aware_level_width(ia):
     assert ia.circuit_level_cap(5, 64, 128) == 80        # 80 x 128 = ten rounds: what the default schedule already does
     assert ia.circuit_level_cap(4, 128, 1024) == 0       # a whole round per gate of a level: nothing to quantise
     assert ia.circuit_level_cap(4, 128, 2) == 0          # under one round per level: narrow levels are the cheap ones
-    assert ia.circuit_level_cap(4, 32, 16) == 0          # ASAP-scheduled circuits keep their levels
+    # the ASAP-scheduled 32-bit multiplier family at small batches: floor(m x resident / batch) gates per expression, m = the
+    # whole number of rounds nearest its mean level (44 gates per expression); nothing for adders, the shallow carry-save
+    # trees, or batches whose mean level is already three rounds or more
+    assert ia.circuit_level_cap(4, 32, 58, 2048) == 35 and ia.circuit_level_cap(4, 32, 64, 2048) == 32
+    assert ia.circuit_level_cap(5, 32, 100, 2048) == 40  # two rounds per level
+    assert ia.circuit_level_cap(4, 32, 16, 2048) == 0 and ia.circuit_level_cap(4, 32, 256, 2048) == 0
+    assert ia.circuit_level_cap(4, 32, 1024, 2048) == 0  # BASELINE configs[2] keeps cloud.c's ASAP levels
+    assert ia.circuit_level_cap(1, 32, 58, 2048) == 0 and ia.circuit_level_cap(ia.CIRC_MUL_WALLACE, 32, 8, 2048) == 0
+    c35 = ia.circuit_info(4, 32, level_cap=35)
+    assert c35.sched_levels == 334 and c35.sched_max_width <= 36 and c35.bootstraps == 11264
+    x = rng.integers(0, 2, size=ia.circuit_info(4, 32).n_inputs, dtype=np.uint8)
+    assert np.array_equal(ia.circuit_simulate(4, 32, x), ia.circuit_simulate(4, 32, x, level_cap=35))
     assert ia.circuit_level_cap(ia.CIRC_MUL_WALLACE, 128, 16) == 0  # no slack to flatten
     assert ia.circuit_level_cap(4, 64, 100) == 0         # quantum 256 is beyond what a level offers
     base, capped = ia.circuit_info(4, 64), ia.circuit_info(4, 64, level_cap=64)
@@ -220,7 +231,7 @@ def test_batch_aware_level_width(ia):
         assert np.array_equal(ia.circuit_simulate(4, 64, x), ia.circuit_simulate(4, 64, x, level_cap=64))
     x = rng.integers(0, 2, size=ia.circuit_info(5, 64).n_inputs, dtype=np.uint8)
     assert np.array_equal(ia.circuit_simulate(5, 64, x), ia.circuit_simulate(5, 64, x, level_cap=64))
-    assert ia.circuit_info(4, 32, level_cap=64).sched_levels == 255  # ignored where the schedule is ASAP
+    assert ia.circuit_info(1, 32, level_cap=64).sched_levels == 96   # ignored where there is nothing to balance
 
 
 @pytest.mark.parametrize("bits", [1, 5, 16, 32, 64, 256])

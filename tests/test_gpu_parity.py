@@ -809,6 +809,20 @@ def test_batch_aware_level_width_same_bits(ia, gpu_ctx):
     assert st0.levels == 449 and np.array_equal(out, ref)
     from ieache_amd.tools import bits_to_int
     assert [bits_to_int(d) for d in kb.dec(out)] == [a * b for a, b in vals]
+    # the ASAP-scheduled 32-bit multiplier at a small batch: 58 expressions get levels of 35 gates (58 x 35 = one round)
+    vals32 = [(int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))) for _ in range(58)]
+    inp32 = _inputs(kb, 4, 32, vals32, 34)
+    st = ia.Stats()
+    out32 = ctx.eval_batch(4, 32, inp32, st)
+    assert st.levels == ia.circuit_info(4, 32, level_cap=35).sched_levels == 334 and st.bootstraps == 58 * 11264
+    ctx.set_option("level_quantum", 0)
+    try:
+        st0 = ia.Stats()
+        ref32 = ctx.eval_batch(4, 32, inp32, st0)
+    finally:
+        ctx.set_option("level_quantum", 1)
+    assert st0.levels == 255 and np.array_equal(out32, ref32)
+    assert [bits_to_int(d) for d in kb.dec(out32)] == [a * b for a, b in vals32]
 
 
 def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
