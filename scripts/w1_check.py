@@ -15,7 +15,7 @@ b = tools.encrypt_bits(p, k["lwe_key"], bits[1], 12)
 ctx.set_option("exact_fft", 1)
 ref = ctx.gates(ia.GATE_XOR, a, b)
 ctx.set_option("exact_fft", 0)
-for variant, counts in ((24, (1, 37, 256)), (7, (1, 256))):
+for variant, counts in ((13, (4099, 8192)), (20, (600, 1024)), (24, (1, 37, 256)), (7, (1, 256))):
     ctx.set_option("br_variant", variant)
     for c in counts:
         best = None
