@@ -88,7 +88,8 @@ public:
     // 2L-waves-per-gate kernel; default = the device's CU count, 0 = never), "br_variant",
     // "exact_fft" (1 = two-limb blind rotation always), "one_limb_min" (launches of at least this many gate
     // instances use the one-limb kernels; default: one per CU + 1), "two_wave_max" (of those, launches up to this many
-    // gate instances take two waves per gate, k_blind_rotate_w2s; default 4 per CU).
+    // gate instances take two waves per gate, k_blind_rotate_w2s; default 4 per CU), "fft_guard_inject" (test hook: 1 makes
+    // the next call find the rounding guard tripped, so that it repeats itself on the two-limb kernels).
     // Returns false for an unknown name or a value out of range.
     bool set_option(const std::string& name, int64_t value);
     std::string kernel_variant() const;
