@@ -6,15 +6,19 @@
 One "step" = one pass of a whole circuit (every level, every gate) over one
 batch of expressions whose ciphertexts are already resident in HBM.  The timed
 K steps run the primary workload = BASELINE.json configs[1]: 16-bit ADD, batch
-4096 per GPU.  The default invocation then adds a second timed leg on the same
-resident key: ONE full pass of configs[2] (32-bit shift-add MUL, batch 1024 per
-GPU, every product decrypt-checked) -> the `mul32` object of the JSON line
-(gate ops/s, encrypted 32-bit MUL/s, its own roofline), and one pass of the
-opt-in constant-folded multiplier (`mul32.folded`).  For N>1 launch through
-torch.distributed.run (one rank per GPU); expressions shard across ranks with
-no data-path collective (weak scaling: the per-GPU batch is fixed), after a
-one-time RCCL broadcast of the bootstrapping / key-switch key.  Rank 0 prints
-ONE JSON line.
+4096 per GPU.  The default invocation then adds, on the same resident key, one
+full timed pass each of
+  * configs[2]: 32-bit shift-add MUL, batch 1024 per GPU   -> `mul32`   (gate ops/s, encrypted 32-bit MUL/s)
+  * configs[3]'s per-GPU share: 64-bit a*b+c, batch 128     -> `muladd64`
+  * configs[4]'s circuit: 128-bit MUL, a time-boxed sub-batch of 128 of its 1024 per GPU -> `mul128`
+every product decrypt-checked, each with its own roofline object.  (--extras adds the two opt-in,
+decrypt-identical-only multipliers: constant-folded and carry-save.)
+
+N > 1: `python bench.py --gpus N ...` starts its own ranks (python -m torch.distributed.run, one
+child process per GPU, before this process touches the GPU) unless it already runs under
+torch.distributed.run (WORLD_SIZE set).  Expressions shard across ranks with no data-path
+collective (weak scaling: the per-GPU batch is fixed), after a one-time RCCL broadcast of the
+bootstrapping / key-switch key.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -30,9 +34,19 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP64_VALU_PEAK_TFLOPS = 78.6          # 256 CUs x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-LANES, FLOP_PER_INST = 64, 2          # one wave-instruction = 64 lanes; priced as an FMA (2 flop) like the peak
-# (the FP64 instructions among them -- the part of the vector issue that is the algorithm itself -- are counted in the
-# kernel's ISA and recorded next to the counters in profiles/traffic.json: fp64_insts_per_gate_step)
+LANES, FLOP_PER_INST = 64, 2          # one wave-instruction = 64 lanes; an FMA is 2 flop, like the peak
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave-instructions/s the chip can issue: 256 CUs x 4 SIMDs, one per 4 cycles at 2.4 GHz
+
+
+def algorithmic_flops_per_gate(p):
+    """per CMux step (k+1)l forward + (k+1) inverse negacyclic transforms of N/2 complex points
+    (5 M log2 M flop each) + (k+1)^2 l M complex multiply-accumulates (8 flop each); times n steps.
+    n=630, N=1024, k=1, l=3: 233 472 flop per step, 1.47e8 per gate."""
+    M = p.N // 2
+    logM = M.bit_length() - 1
+    per_step = ((p.k + 1) * p.l + (p.k + 1)) * 5 * M * logM + (p.k + 1) ** 2 * p.l * M * 8
+    return per_step * p.n
+
 
 WORKLOADS = {
     # name: (circuit kind, bits, default per-GPU batch, BASELINE.json config)
@@ -63,7 +77,9 @@ def pmc_counters(kernel_variant):
             return None
         out = {"kernel": tj.get("kernel"), "fp64_insts_per_gate_step": tj.get("fp64_insts_per_gate_step", 0),
                "hbm_bytes_per_gate_step": tj["hbm_bytes_per_gate_step"], "l2_hit_rate": tj.get("l2_hit_rate"),
-               "source": tj.get("pmc_summary", tj.get("source")), "shader_cycles_per_gate_step": tj.get("shader_cycles_per_gate_step")}
+               "source": tj.get("pmc_summary", tj.get("source")), "shader_cycles_per_gate_step": tj.get("shader_cycles_per_gate_step"),
+               "gates_per_launch": tj.get("gates_per_launch"), "cmux_steps_per_launch": tj.get("cmux_steps_per_launch"),
+               "rocprof_avg_launch_ms": tj.get("rocprof_avg_launch_ms"), "rocprof_stats": tj.get("rocprof_stats")}
         summ = tj.get("pmc_summary")
         if summ:
             for line in open(os.path.join(ROOT, summ)):
@@ -76,8 +92,14 @@ def pmc_counters(kernel_variant):
 
 
 def roofline(p, stats, gate_rate, pmc):
-    """The record for one timed leg.  Primary bound: FP64 vector issue of the blind rotation (BK is shared
-    by every gate of a launch out of L2, so HBM is not what limits it: see hbm_model.reuse_factor).
+    """The record for one timed leg, for its dominant kernel (the blind rotation).
+
+    bound fp64_valu: BK is shared by every gate of a launch out of L2 (hbm_model.reuse_factor), so what limits the
+    kernel is the FP64 vector pipe.  `achieved` = ALGORITHMIC flops of one launch (233 472 flop per
+    gate and CMux step x the gate-steps the launch processes) / its average duration (HIP events on the evaluator's
+    own stream, around the kernel's launches only); `frac` = that / the dense FP64 vector peak.  `valu_issue` says how
+    full the vector ISSUE slots are (every instruction counted once, whatever it does: FP64 FMAs and adds, index
+    arithmetic, cross-lane moves) -- a utilisation of the pipe, not a flop rate.
     hbm_model is SURVEY 8(d)'s streaming-model figure, priced end to end on the leg's own rate."""
     bk_b, ksk_b, io_b = algorithmic_bytes(p)
     per_gate = bk_b + ksk_b + io_b
@@ -88,32 +110,43 @@ def roofline(p, stats, gate_rate, pmc):
     steps_per_launch = p.n / max(1.0, launches_per_gate)
     br_gate_rate = stats.bootstraps / max(1e-9, stats.blind_rotate_ms * 1e-3)   # gates/s of the blind rotation alone
     ks_gate_rate = stats.bootstraps / max(1e-9, stats.keyswitch_ms * 1e-3)
-    insts = pmc.get("valu_insts_per_gate_step") if pmc else None
     traffic = pmc["hbm_bytes_per_gate_step"] * gates_per_launch * steps_per_launch if pmc else None
-    out = {"kernel": (pmc or {}).get("kernel", "k_blind_rotate"), "avg_launch_ms": br_avg_ms, "gates_per_launch": gates_per_launch,
-           "cmux_steps_per_launch": steps_per_launch, "traffic": traffic,
+    alg_flop = algorithmic_flops_per_gate(p)
+    achieved = br_gate_rate * alg_flop * 1e-12
+    out = {"bound": "fp64_valu", "unit": "TFLOP/s", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
+           "frac": achieved / FP64_VALU_PEAK_TFLOPS, "frac_algorithmic_flops": achieved / FP64_VALU_PEAK_TFLOPS,
+           "traffic": traffic,
+           "kernel": (pmc or {}).get("kernel", "k_blind_rotate"), "avg_launch_ms": br_avg_ms,
+           "gates_per_launch": gates_per_launch, "cmux_steps_per_launch": steps_per_launch,
+           "algorithmic_flops_per_gate": alg_flop,
+           "algorithmic_flops_per_launch": alg_flop * gates_per_launch * steps_per_launch / p.n,
+           "rocprof_avg_launch_ms": (pmc or {}).get("rocprof_avg_launch_ms"), "rocprof_stats": (pmc or {}).get("rocprof_stats"),
            "blind_rotate_share": stats.blind_rotate_ms / max(1e-9, stats.total_ms),
-           "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms)}
+           "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms),
+           "note": "achieved = SURVEY 8(d) algorithmic flops (8 transforms x 5 M log2 M + 12 M complex MACs per CMux step) of a launch / its "
+                   "HIP-event duration; 100 %% = %.0f gates/s per GPU.  rocprof_avg_launch_ms: the same kernel's average in the committed "
+                   "rocprofv3 --kernel-trace --stats summary (rocprof_stats), at the geometry named there" % (FP64_VALU_PEAK_TFLOPS * 1e12 / alg_flop)}
+    insts = pmc.get("valu_insts_per_gate_step") if pmc else None
     if insts:
-        flop_per_gate = insts * p.n * LANES * FLOP_PER_INST
-        out.update({"bound": "fp64_valu", "unit": "TFLOP/s",
-                    "achieved": br_gate_rate * flop_per_gate * 1e-12, "peak": FP64_VALU_PEAK_TFLOPS,
-                    "frac": br_gate_rate * flop_per_gate * 1e-12 / FP64_VALU_PEAK_TFLOPS,
-                    "valu_insts_per_gate": insts * p.n, "valu_insts_source": pmc.get("source"),
-                    "frac_fp64_only": br_gate_rate * pmc.get("fp64_insts_per_gate_step", 0) * p.n * LANES * FLOP_PER_INST * 1e-12 / FP64_VALU_PEAK_TFLOPS,
-                    "note": "achieved = blind-rotation gates/s (HIP events over its launches) x SQ_INSTS_VALU per gate x 64 lanes x 2 flop "
-                            "= vector-issue utilisation (index arithmetic and cross-lane moves included; frac_fp64_only counts the FP64 instructions alone); "
-                            "100 %% = %.0f gates/s per GPU at 2.4 GHz" % (FP64_VALU_PEAK_TFLOPS * 1e12 / flop_per_gate)})
+        vi = {"insts_per_gate_step": insts, "fp64_insts_per_gate_step": pmc.get("fp64_insts_per_gate_step", 0),
+              "utilisation": br_gate_rate * insts * p.n / VALU_ISSUE_PEAK,
+              "utilisation_fp64_insts_only": br_gate_rate * pmc.get("fp64_insts_per_gate_step", 0) * p.n / VALU_ISSUE_PEAK,
+              "source": pmc.get("source"),
+              "pmc_geometry": {"gates_per_launch": pmc.get("gates_per_launch"), "cmux_steps_per_launch": pmc.get("cmux_steps_per_launch")},
+              "note": "vector-issue slots: SQ_INSTS_VALU per gate-step (PMC pass, geometry above) x this leg's gate-steps/s over 256 CUs x 4 SIMDs x "
+                      "2.4 GHz / 4 cycles; every vector instruction counts as one slot -- not a flop rate"}
+        # the per-gate-step count does not depend on the launch size, but say so when the geometries differ
+        g = vi["pmc_geometry"]
+        vi["geometry_differs_from_pmc_run"] = bool(g["gates_per_launch"] and (abs(g["gates_per_launch"] - gates_per_launch) > 0.5 or
+                                                                              abs((g["cmux_steps_per_launch"] or 0) - steps_per_launch) > 0.5))
         cyc = pmc.get("shader_cycles_per_gate_step")
         if cyc and br_avg_ms > 0:
             # the chip lowers its clock under this load (DVFS give-back): shader cycles of a launch from GRBM_GUI_ACTIVE / 8
             # (PMC run, scaled to this leg's launch geometry) over the launch time measured here
             ghz = cyc * gates_per_launch * steps_per_launch / (br_avg_ms * 1e-3) / 1e9
-            out["effective_clock_GHz"] = ghz
-            out["frac_at_effective_clock"] = out["frac"] * 2.4 / ghz
-    else:
-        out.update({"bound": "fp64_valu", "unit": "TFLOP/s", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "frac": None,
-                    "note": "no committed SQ_INSTS_VALU for this kernel variant"})
+            vi["effective_clock_GHz"] = ghz
+            vi["utilisation_at_effective_clock"] = vi["utilisation"] * 2.4 / ghz
+        out["valu_issue"] = vi
     measured_gbs = (traffic / (br_avg_ms * 1e-3) / 1e9) if (traffic and br_avg_ms > 0) else None
     alg_launch = per_gate * gates_per_launch * steps_per_launch / p.n
     out["hbm_model"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -121,13 +154,15 @@ def roofline(p, stats, gate_rate, pmc):
                         "algorithmic_bytes_per_gate": per_gate, "algorithmic_bytes_per_launch": alg_launch,
                         "measured_hbm_bytes_per_launch": traffic, "measured_hbm_GBps": measured_gbs,
                         "reuse_factor": (alg_launch / traffic) if traffic else None,
-                        "note": "streaming model (every gate streams BK and its KSK rows once), priced end to end on this leg's gate rate; "
+                        "note": "streaming model (every gate streams BK and its KSK rows once), priced end to end on this leg's gate rate: "
+                                "above 1 means BK is reused out of L2, not that HBM is saturated; "
                                 "measured = FETCH_SIZE x2 + WRITE_SIZE of the blind-rotation launches (PMC, gfx950 correction)"}
     out["per_kernel"] = {
-        "blind_rotate": {"algorithmic_bytes_per_gate": bk_b, "achieved_GBps": br_gate_rate * bk_b / 1e9,
-                         "frac_of_hbm": br_gate_rate * bk_b / 1e9 / HBM_PEAK_GBS, "gates_per_s": br_gate_rate, "avg_launch_ms": br_avg_ms},
-        "keyswitch": {"algorithmic_bytes_per_gate": ksk_b, "achieved_GBps": ks_gate_rate * ksk_b / 1e9,
-                      "frac_of_hbm": ks_gate_rate * ksk_b / 1e9 / HBM_PEAK_GBS, "gates_per_s": ks_gate_rate, "avg_launch_ms": ks_avg_ms}}
+        "blind_rotate": {"algorithmic_bytes_per_gate": bk_b, "model_GBps": br_gate_rate * bk_b / 1e9,
+                         "gates_per_s": br_gate_rate, "avg_launch_ms": br_avg_ms},
+        "keyswitch": {"algorithmic_bytes_per_gate": ksk_b, "model_GBps": ks_gate_rate * ksk_b / 1e9,
+                      "gates_per_s": ks_gate_rate, "avg_launch_ms": ks_avg_ms,
+                      "note": "model_GBps = streaming-model bytes x rate; the rows are served from L2 / Infinity Cache (profiles/traffic.json: keyswitch_sliced)"}}
     return out
 
 
@@ -258,6 +293,31 @@ def progress(rank, msg):
         print("[bench %6.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves, as a child process tree
+    (never exec: this must also work where a GPU-initialised process may not be replaced), relay rank 0's JSON line on
+    stdout and the ranks' progress on stderr, return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("[bench] --gpus %d without a torch.distributed.run environment: starting %d ranks (rendezvous 127.0.0.1:%d)"
+          % (args.gpus, args.gpus, port), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:  # rank 0's one JSON line (and nothing else) goes to our stdout
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+# the legs that follow the primary one in the default invocation: (key, workload, per-GPU batch, full per-GPU batch of the config)
+DEFAULT_LEGS = (("mul32", "mul32", 1024, 1024), ("muladd64", "muladd64", 128, 128), ("mul128", "mul128", 128, 1024))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,13 +328,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--mul32-leg", default="auto", choices=["auto", "on", "off"],
-                    help="second timed leg: one pass of mul32 x --mul32-batch (auto: on for the default workload at its default batch)")
+    ap.add_argument("--legs", default="auto",
+                    help="comma-separated extra legs after the primary one, each ONE full timed pass: mul32, muladd64, mul128 "
+                         "(auto: all three for the default workload at its default batch; none: primary leg only)")
+    ap.add_argument("--mul32-leg", default="auto", choices=["auto", "on", "off"], help="(kept for older command lines) on = --legs mul32")
     ap.add_argument("--mul32-batch", type=int, default=1024)
-    ap.add_argument("--no-folded", action="store_true", help="skip the constant-folded pass of the mul32 leg")
+    ap.add_argument("--muladd64-batch", type=int, default=128)
+    ap.add_argument("--mul128-batch", type=int, default=128)
+    ap.add_argument("--time-box", type=float, default=330.0,
+                    help="a leg is skipped (and named in `skipped_legs`) when the run has already taken this many seconds minus the leg's estimate")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time the two opt-in, decrypt-identical-only 32-bit multipliers (constant-folded, carry-save) in the mul32 leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearse the N>1 flow with CPU collectives (ranks may then share one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # before anything touches the GPU in this process
 
     import torch
     import ieache_amd as ia
@@ -284,10 +354,7 @@ def main():
     rank, world, local_rank, dist = parallel.init_distributed(args.backend)
     if args.backend == "gloo":
         local_rank %= max(1, torch.cuda.device_count())  # rehearsal: ranks wrap around the GPUs present
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -324,68 +391,60 @@ def main():
     stats = ia.Stats()
     progress(rank, "%s x%d: warm-up done, every expression decrypts; timing %d steps" % (args.workload, batch, args.steps))
     elapsed, per_rank = timed(torch, dist, world, dev, args.backend, lambda: [step(stats) for _ in range(args.steps)])
-    progress(rank, "%s x%d: %.0f gate ops/s" % (args.workload, batch, info.bootstraps * batch * args.steps * world / elapsed))
+    primary_rate = info.bootstraps * batch * args.steps * world / elapsed
+    progress(rank, "%s x%d: %.0f gate ops/s" % (args.workload, batch, primary_rate))
     del d_in, d_out
 
-    # ---- second leg: BASELINE configs[2], the metric's "encrypted 32-bit MUL/sec" ----
-    mul_leg = None
-    want_mul = args.mul32_leg == "on" or (args.mul32_leg == "auto" and args.workload == "add16" and not args.batch)
-    if want_mul:
-        mb = args.mul32_batch
-        minfo, minb, md_in, md_out = make_inputs(ia, tools, torch, ctx, p, lwe_key, 4, 32, mb, rank, dev, 5000)
-        mst = ia.Stats()
-        m_elapsed, m_per_rank = timed(torch, dist, world, dev, args.backend,
-                                      lambda: ctx.eval_batch_device(4, 32, mb, md_in.data_ptr(), md_out.data_ptr(), mst))
-        check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)  # all `mb` products, after the timed pass
-        progress(rank, "mul32 x%d: %.2f MUL/s" % (mb, mb * world / m_elapsed))
-        folded = None
-        if not args.no_folded:
-            finfo = ia.circuit_info(4, 32, fold=True)
-            ctx.set_option("fold_constants", 1)
-            fst = ia.Stats()
-            f_elapsed, _ = timed(torch, dist, world, dev, args.backend,
-                                 lambda: ctx.eval_batch_device(4, 32, mb, md_in.data_ptr(), md_out.data_ptr(), fst))
-            ctx.set_option("fold_constants", 0)
-            check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)
-            progress(rank, "mul32 x%d, constants folded: %.2f MUL/s" % (mb, mb * world / f_elapsed))
-            folded = {"flag": "fold_constants=1 (IEACHE_FOLD=1): constant operands folded, repeated gates shared; decrypt-identical, "
-                              "NOT the reference's ciphertext bits; never the default",
-                      "executed_bootstraps_per_expr": int(finfo.bootstraps), "reference_bootstraps_per_expr": int(finfo.reference_bootstraps),
-                      "levels": int(finfo.depth), "ms_per_pass": f_elapsed * 1e3,
-                      "mul32_per_s": mb * world / f_elapsed,
-                      "executed_gate_ops_per_s": int(finfo.bootstraps) * mb * world / f_elapsed,
-                      "reference_equivalent_gate_ops_per_s": int(finfo.reference_bootstraps) * mb * world / f_elapsed,
-                      "speedup_vs_reference_circuit": m_elapsed / f_elapsed, "checked": "all %d products decrypt to a*b" % mb}
-        # third pass, also opt-in and decrypt-identical only: the carry-save multiplier (37 levels, 6 637 bootstraps);
-        # skipped when the run is already long, so that the default invocation stays well inside the driver's limit
-        carry_save = None
+    # ---- the other configs, one full timed pass each on the same resident key ----
+    if args.legs == "auto":
+        legs = [l[0] for l in DEFAULT_LEGS] if (args.workload == "add16" and not args.batch and args.mul32_leg != "off") else []
+        if args.mul32_leg == "on" and "mul32" not in legs:
+            legs = ["mul32"]
+    else:
+        legs = [l for l in args.legs.split(",") if l and l != "none"]
+    leg_batch = {"mul32": args.mul32_batch, "muladd64": args.muladd64_batch, "mul128": args.mul128_batch}
+    leg_out, skipped = {}, []
+    for key, wl, _, full_batch in DEFAULT_LEGS:
+        if key not in legs:
+            continue
+        lkind, lbits, _, lname = WORKLOADS[wl]
+        lb = leg_batch[key]
+        linfo = ia.circuit_info(lkind, lbits)
+        # one decision for all ranks (the pass contains barriers): skip a leg the time box has no room for
+        estimate = int(linfo.bootstraps) * lb / max(1.0, primary_rate / world)
         so_far = time.perf_counter() - T_START
-        if world > 1:  # one decision for all ranks (the pass below contains barriers)
+        if world > 1:
             t = torch.tensor([so_far], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             so_far = float(t.item())
-        if not args.no_folded and so_far < 360.0:
-            winfo = ia.circuit_info(ia.CIRC_MUL_WALLACE, 32)
-            wst = ia.Stats()
-            w_elapsed, _ = timed(torch, dist, world, dev, args.backend,
-                                 lambda: ctx.eval_batch_device(ia.CIRC_MUL_WALLACE, 32, mb, md_in.data_ptr(), md_out.data_ptr(), wst))
-            check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)
-            progress(rank, "mul32 x%d, carry-save multiplier: %.2f MUL/s" % (mb, mb * world / w_elapsed))
-            carry_save = {"flag": "IEACHE_CIRC_MUL_WALLACE (IEACHE_MULTIPLIER=wallace): Dadda carry-save tree + Kogge-Stone add; "
-                                  "decrypt-identical, NOT the reference's gate sequence; never the default",
-                          "executed_bootstraps_per_expr": int(winfo.bootstraps), "reference_bootstraps_per_expr": int(winfo.reference_bootstraps),
-                          "levels": int(winfo.depth), "ms_per_pass": w_elapsed * 1e3, "mul32_per_s": mb * world / w_elapsed,
-                          "executed_gate_ops_per_s": int(winfo.bootstraps) * mb * world / w_elapsed,
-                          "speedup_vs_reference_circuit": m_elapsed / w_elapsed, "checked": "all %d products decrypt to a*b" % mb}
-        if rank == 0:
-            m_rate = int(minfo.bootstraps) * mb * world / m_elapsed
-            mul_leg = {"workload": WORKLOADS["mul32"][3], "batch_per_gpu": mb, "bootstraps_per_expr": int(minfo.bootstraps),
-                       "levels": int(minfo.depth), "passes": 1, "ms_per_pass": m_elapsed * 1e3,
-                       "gate_ops_per_s": m_rate, "mul32_per_s": mb * world / m_elapsed,
-                       "per_rank_gate_ops_per_s": [int(minfo.bootstraps) * mb / t for t in m_per_rank],
-                       "checked": "all %d products of the timed pass decrypt to a*b" % mb,
-                       "roofline": roofline(p, mst, m_rate / world, pmc), "folded": folded, "carry_save": carry_save}
-        del md_in, md_out
+        if so_far + estimate > args.time_box:
+            skipped.append({"leg": key, "reason": "%.0f s elapsed + %.0f s estimated > --time-box %.0f s" % (so_far, estimate, args.time_box)})
+            progress(rank, "%s x%d skipped: time box" % (key, lb))
+            continue
+        linfo, linb, ld_in, ld_out = make_inputs(ia, tools, torch, ctx, p, lwe_key, lkind, lbits, lb, rank, dev, 5000 + 1000 * len(leg_out))
+        lst = ia.Stats()
+        l_elapsed, l_per_rank = timed(torch, dist, world, dev, args.backend,
+                                      lambda: ctx.eval_batch_device(lkind, lbits, lb, ld_in.data_ptr(), ld_out.data_ptr(), lst))
+        check_outputs(tools, p, lwe_key, lkind, lbits, linb, ld_out, rank)  # every expression, after the timed pass
+        l_rate = int(linfo.bootstraps) * lb * world / l_elapsed
+        progress(rank, "%s x%d: %.0f gate ops/s, %.2f expressions/s" % (key, lb, l_rate, lb * world / l_elapsed))
+        rec = {"workload": lname, "circuit": "%s%d" % (wl.rstrip("0123456789"), lbits), "batch_per_gpu": lb,
+               "bootstraps_per_expr": int(linfo.bootstraps), "levels": int(linfo.depth), "passes": 1, "ms_per_pass": l_elapsed * 1e3,
+               "gate_ops_per_s": l_rate, "expressions_per_s": lb * world / l_elapsed,
+               "per_rank_gate_ops_per_s": [int(linfo.bootstraps) * lb / t for t in l_per_rank],
+               "checked": "all %d expressions of the timed pass decrypt to the integer result" % lb,
+               "roofline": roofline(p, lst, l_rate / world, pmc)}
+        if lb != full_batch:
+            rec["sub_batch_of"] = full_batch
+            rec["full_share_estimate_s"] = l_elapsed * full_batch / lb
+            rec["note"] = ("time-boxed sub-batch: %d of the config's %d expressions per GPU; the circuit's levels are whole rounds of resident gates "
+                           "from batch 128 on, so the full share takes %d/%d x this pass" % (lb, full_batch, full_batch, lb))
+        if key == "mul32":
+            rec["mul32_per_s"] = lb * world / l_elapsed
+            if args.extras:
+                rec.update(mul32_extras(ia, tools, torch, dist, world, dev, args, ctx, p, lwe_key, lb, linb, ld_in, ld_out, rank, l_elapsed))
+        leg_out[key] = rec
+        del ld_in, ld_out
 
     if rank == 0:
         gates_total = info.bootstraps * batch * args.steps * world
@@ -407,20 +466,21 @@ def main():
                        "batch_per_gpu": batch, "bootstraps_per_expr": int(info.bootstraps), "levels": int(info.depth),
                        "params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2",
                        "arithmetic": "Torus32 = int32 with wraparound; the negacyclic products inside the external product run as one f64 transform "
-                                     "of the 32-bit coefficients with a rounding guard (bit-identical to the two-limb exact transform, which "
-                                     "exact_fft=1 selects; fft_guard below)",
+                                     "of the 32-bit coefficients with a rounding guard and a sampled two-limb audit (bit-identical to the two-limb "
+                                     "exact transform, which exact_fft=1 selects; fft_guard below)",
                        "parallelism": "batch-sharded x%d" % world, "kernel": ctx.kernel_variant,
                        "key_broadcast_s": round(t_bcast, 4),
                        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
                        "collective_backend": args.backend if world > 1 else None,
                        "per_rank_gate_ops_per_s": [info.bootstraps * batch * args.steps / t for t in per_rank]},
             "roofline": roofline(p, stats, value / world, pmc),
-            "fft_guard": dict(zip(("max_rounding_deviation", "reruns_on_two_limb_kernel"), ctx.fft_guard()),
-                              limit=1.0 / 16, wrong_bit_at=0.5),
+            "fft_guard": fft_guard_record(ctx),
         }
-        if mul_leg:
-            out["mul32"] = mul_leg
-            out["mul32_per_s"] = mul_leg["mul32_per_s"]
+        out.update(leg_out)
+        if skipped:
+            out["skipped_legs"] = skipped
+        if "mul32" in leg_out:
+            out["mul32_per_s"] = leg_out["mul32"]["mul32_per_s"]
         elif kind == 4 and bits == 32:
             out["mul32_per_s"] = batch * args.steps * world / elapsed
         if world == 1 and not args.no_cpu_baseline:
@@ -429,6 +489,47 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def fft_guard_record(ctx):
+    dev_max, reruns = ctx.fft_guard()
+    rec = {"max_rounding_deviation": dev_max, "reruns_on_two_limb_kernel": reruns, "limit": 1.0 / 16, "wrong_bit_at": 0.5}
+    audit = getattr(ctx, "fft_audit", None)
+    if audit is not None:
+        rec["audit"] = audit()
+    return rec
+
+
+def mul32_extras(ia, tools, torch, dist, world, dev, args, ctx, p, lwe_key, mb, minb, md_in, md_out, rank, m_elapsed):
+    """--extras: the two opt-in 32-bit multipliers (decrypt-identical, NOT the reference's ciphertext bits; never the default)."""
+    finfo = ia.circuit_info(4, 32, fold=True)
+    ctx.set_option("fold_constants", 1)
+    fst = ia.Stats()
+    f_elapsed, _ = timed(torch, dist, world, dev, args.backend,
+                         lambda: ctx.eval_batch_device(4, 32, mb, md_in.data_ptr(), md_out.data_ptr(), fst))
+    ctx.set_option("fold_constants", 0)
+    check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)
+    progress(rank, "mul32 x%d, constants folded: %.2f MUL/s" % (mb, mb * world / f_elapsed))
+    folded = {"flag": "fold_constants=1 (IEACHE_FOLD=1): constant operands folded, repeated gates shared; decrypt-identical, "
+                      "NOT the reference's ciphertext bits; never the default",
+              "executed_bootstraps_per_expr": int(finfo.bootstraps), "reference_bootstraps_per_expr": int(finfo.reference_bootstraps),
+              "levels": int(finfo.depth), "ms_per_pass": f_elapsed * 1e3, "mul32_per_s": mb * world / f_elapsed,
+              "executed_gate_ops_per_s": int(finfo.bootstraps) * mb * world / f_elapsed,
+              "reference_equivalent_gate_ops_per_s": int(finfo.reference_bootstraps) * mb * world / f_elapsed,
+              "speedup_vs_reference_circuit": m_elapsed / f_elapsed, "checked": "all %d products decrypt to a*b" % mb}
+    winfo = ia.circuit_info(ia.CIRC_MUL_WALLACE, 32)
+    wst = ia.Stats()
+    w_elapsed, _ = timed(torch, dist, world, dev, args.backend,
+                         lambda: ctx.eval_batch_device(ia.CIRC_MUL_WALLACE, 32, mb, md_in.data_ptr(), md_out.data_ptr(), wst))
+    check_outputs(tools, p, lwe_key, 4, 32, minb, md_out, rank)
+    progress(rank, "mul32 x%d, carry-save multiplier: %.2f MUL/s" % (mb, mb * world / w_elapsed))
+    carry_save = {"flag": "IEACHE_CIRC_MUL_WALLACE (IEACHE_MULTIPLIER=wallace): Dadda carry-save tree + Kogge-Stone add; "
+                          "decrypt-identical, NOT the reference's gate sequence; never the default",
+                  "executed_bootstraps_per_expr": int(winfo.bootstraps), "reference_bootstraps_per_expr": int(winfo.reference_bootstraps),
+                  "levels": int(winfo.depth), "ms_per_pass": w_elapsed * 1e3, "mul32_per_s": mb * world / w_elapsed,
+                  "executed_gate_ops_per_s": int(winfo.bootstraps) * mb * world / w_elapsed,
+                  "speedup_vs_reference_circuit": m_elapsed / w_elapsed, "checked": "all %d products decrypt to a*b" % mb}
+    return {"folded": folded, "carry_save": carry_save}
 
 
 if __name__ == "__main__":

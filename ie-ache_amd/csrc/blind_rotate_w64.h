@@ -57,6 +57,7 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 int32_t default_variant();
 constexpr int32_t kVariantWide = 7;
 constexpr int32_t kVariantOneLimb = 13;
+constexpr int32_t kVariantOneLimbDefault = 31;  // k_blind_rotate_w1b, guard on one coefficient in four (round 3)
 constexpr int32_t kVariantOneLimbTwoWaves = 20;
 constexpr int32_t kVariantWideOneLimb = 22;
 constexpr int32_t kVariantWideHandoverOneLimb = 24;

@@ -882,6 +882,354 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
     }
 }
 
+// ---- K3 (+K4), throughput form, round 3: k_blind_rotate_w1 with fewer non-FP64 instructions ----
+// Same mapping, same transforms, same BK schedule as k_blind_rotate_w1; what changed is everything around the FP64 work:
+//   * the accumulators stand FIRST in the workgroup's LDS, each polynomial on a 4 KiB boundary, so the byte address of
+//     coefficient (j - a) mod N is one v_and_or_b32 of a per-step lane value plus 256 r, and the address of coefficient
+//     j + 512 is that address ^ 2048 (before: and / shift / add per coefficient);
+//   * the negacyclic sign is a v_bfe_i32 of the same per-step value (before: and, compare, select);
+//   * (X^a - 1) acc + offset is formed as (rot ^ m) + ((offset - acc_j) - m)  (v_xad_u32);
+//   * GUARD = 2 folds the distance to the nearest integer of ONE rounded coefficient in four into the running maximum
+//     (registers r = 0 and r = 4 of both output polynomials: 8 of 32 per lane and step) -- the guard is a monitor of the
+//     error LEVEL of a launch, and a quarter of ~10^8 coefficients per launch is the same monitor;
+//     the evaluator's audit (every K-th launch re-run on the two-limb kernel, evaluator.hip) is the per-bit check;
+//   * XMIX: which forward transforms take their lane-high transpose through LDS instead of cross-lane
+//     (0 none, 1 the rows of polynomial 1, 2 every second row): balances vector issue against LDS stores.
+// dynamic LDS: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2          (78 848 B -> 2 per CU)
+template <int L, int BGBIT, int GUARD, int XMIX = 0>
+__global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K, const double2* __restrict__ bkf1,
+                                                                       const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                                       int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
+                                                                       Torus32* ext, unsigned* guard,
+                                                                       const double2* __restrict__ gtw) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int32_t* acc_all = reinterpret_cast<int32_t*>(smem);
+    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)kW1Gates * 2 * kN * 4);
+    double2* sTw = sT_all + kW1Gates * kTile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;
+    int32_t* acc = acc_all + wave * 2 * kN;
+    const int64_t item = (int64_t)blockIdx.x * kW1Gates + wave;
+    load_twiddles(sTw, gtw, tid, 64 * kW1Gates);
+    __syncthreads();  // the only workgroup barrier
+    if (item >= items) return;
+    const LaneRoots R = make_roots(sTw, lane);
+    const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[64 * r + lane] = src[64 * r + lane];
+    }
+    wave_sync();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+    double dev_max = 0.0;
+    constexpr int kRowBytes = 2 * kM * (int)sizeof(double2), kStepBytes = 2 * L * kRowBytes;
+    const __amdgpu_buffer_rsrc_t bk_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(bkf1), (short)0, K.n * kStepBytes, 0x00020000);
+    const int lane16 = lane * (int)sizeof(double2);
+    const unsigned char* accb = reinterpret_cast<const unsigned char*>(acc_all);  // LDS offset 0 of the workgroup
+    const uint32_t pb0 = (uint32_t)wave * (2 * kN * 4);                            // this gate's polynomial 0; polynomial 1 at + 4096
+
+    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
+        if (a == 0) continue;  // wave-uniform; exact arithmetic makes the step a no-op
+        const int bki = i * kStepBytes;
+        double2 s[2][8];
+        uint32_t v0[8], v1[8];
+        // byte offset of coefficient (lane - a) in the 2N-ring [acc, -acc]: bits 2..11 address, bit 12 = negate
+        const uint32_t jb4 = ((uint32_t)(lane - a) & (2 * kN - 1)) << 2;
+        auto decompose = [&](const uint32_t pb) {
+            const int32_t* accp = reinterpret_cast<const int32_t*>(accb + pb);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t t = jb4 + 256u * r;
+                const uint32_t o0 = (t & 4092u) | pb, o1 = o0 ^ 2048u;
+                const int32_t m0 = __builtin_amdgcn_sbfe((int32_t)t, 12, 1), m1 = __builtin_amdgcn_sbfe((int32_t)(t + 2048u), 12, 1);
+                const uint32_t rv0 = *reinterpret_cast<const uint32_t*>(accb + o0), rv1 = *reinterpret_cast<const uint32_t*>(accb + o1);
+                const uint32_t pv0 = (uint32_t)accp[64 * r + lane], pv1 = (uint32_t)accp[64 * r + lane + kM];
+                // +/- rot - acc_j + offset, then ^ offset: digit q's field holds digit ^ halfBg, whose sign-extended value IS the digit
+                v0[r] = ((rv0 ^ (uint32_t)m0) + ((dec_offset - pv0) - (uint32_t)m0)) ^ dec_offset;
+                v1[r] = ((rv1 ^ (uint32_t)m1) + ((dec_offset - pv1) - (uint32_t)m1)) ^ dec_offset;
+            }
+        };
+        auto digit_row = [&](const int sh, const int brow, auto first, auto via_lds) {
+            constexpr bool FIRST = decltype(first)::value;
+            constexpr int XL = decltype(via_lds)::value ? 0 : 1;
+            double2 x[8], bA[8], bB[8];
+            load_bk_block<true>(bA, bk_rsrc, lane16, brow, bkf1);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
+                const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
+                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft512_forward<true, XL, 0>(x, sT, lane, R);
+            load_bk_block<true>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[0][k] = FIRST ? cmulx<false>(x[k], bA[k])
+                                : make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[0][k].x)),
+                                               fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[0][k].y)));
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[1][k] = FIRST ? cmulx<false>(x[k], bB[k])
+                                : make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
+                                               fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
+        };
+        decompose(pb0);
+        digit_row(32 - BGBIT, bki, std::true_type{}, std::false_type{});
+        if (XMIX == 2) {
+#pragma unroll 1
+            for (int row = 1; row < 2 * L; row += 2) {   // odd rows through LDS, even rows cross-lane
+                if (row == L) decompose(pb0 + 4096u);
+                const int q = row >= L ? row - L : row;
+                digit_row(32 - (q + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::true_type{});
+                if (row + 1 < 2 * L) {
+                    if (row + 1 == L) decompose(pb0 + 4096u);
+                    const int q2 = row + 1 >= L ? row + 1 - L : row + 1;
+                    digit_row(32 - (q2 + 1) * BGBIT, bki + (row + 1) * kRowBytes, std::false_type{}, std::false_type{});
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int row = 1; row < L; row++) digit_row(32 - (row + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::false_type{});
+            decompose(pb0 + 4096u);
+#pragma unroll 1
+            for (int row = L; row < 2 * L; row++)
+                digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::integral_constant<bool, XMIX == 1>{});
+        }
+        fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            uint32_t* accc = reinterpret_cast<uint32_t*>(acc) + c * kN;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
+                double t0, t1;
+                if (r == 0) {
+                    if (watched) {
+                        const double zx = s[c][0].x * (1.0 / 512.0), zy = s[c][0].y * (1.0 / 512.0);
+                        t0 = zx + kMagic, t1 = zy + kMagic;
+                        dev_max = fmax(dev_max, fabs(zx - (t0 - kMagic)));
+                        dev_max = fmax(dev_max, fabs(zy - (t1 - kMagic)));
+                    } else {
+                        t0 = fma(s[c][0].x, 1.0 / 512.0, kMagic), t1 = fma(s[c][0].y, 1.0 / 512.0, kMagic);
+                    }
+                } else {
+                    const double2 z = cmulx<true>(s[c][r], untwist_reg(r));
+                    t0 = z.x + kMagic, t1 = z.y + kMagic;
+                    if (watched) {
+                        dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
+                        dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
+                    }
+                }
+                const int32_t j = 64 * r + lane;
+                __hip_atomic_fetch_add(&accc[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&accc[j + kM], (uint32_t)__double2loint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        wave_sync();
+    }
+    if (GUARD) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
+        }
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = lane; j <= kN; j += 64)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[64 * r + lane] = src[64 * r + lane];
+    }
+}
+
+// ---- K3 (+K4), mid-size launches, round 3: two waves per gate, the ROWS split between them ----
+// k_blind_rotate_w2s (below) splits a gate by OUTPUT polynomial: wave w owns output w, so each of its three forward
+// spectra has to reach the partner through LDS -- two workgroup barriers per digit row, six per step, and a lone wave per
+// SIMD spends them waiting.  Here the split is by ROW of BK_i: wave w decomposes accumulator polynomial w, transforms its
+// three digits and multiplies each with BOTH output blocks of its own rows (k_blind_rotate_w1's digit row, three times
+// instead of six), keeping two partial spectrum sums.  Only then do the waves meet: each hands the partial sum of the
+// OTHER output to its partner through its own (idle) tile, adds what it receives, inverse-transforms output w and updates
+// accumulator polynomial w -- two barriers per step.  The next step's decomposition reads polynomial w only, so nothing
+// else crosses waves.  Arithmetic differs from k_blind_rotate_w1 only in the order of two exact-after-rounding FP64 sums.
+// dynamic LDS: acc [2][1024] int32 | sT [2][kTile] double2 | tw [kTwElems] double2       (35 840 B -> 4 per CU)
+template <int L, int BGBIT, int GUARD>
+__global__ __launch_bounds__(128, 2) void k_blind_rotate_w2r(DevKeys K, const double2* __restrict__ bkf1,
+                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                            int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
+                                                            unsigned* guard, const double2* __restrict__ gtw) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int32_t* acc = reinterpret_cast<int32_t*>(smem);
+    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)2 * kN * 4);
+    double2* sTw = sT_all + 2 * kTile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;
+    const double2* sTp = sT_all + (wave ^ 1) * kTile;
+    const int64_t item = (int64_t)blockIdx.x;
+    const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    load_twiddles(sTw, gtw, tid, 128);
+    const LaneRoots R = make_roots(sTw, lane);
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[128 * r + tid] = src[128 * r + tid];
+    }
+    __syncthreads();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+    double dev_max = 0.0;
+    constexpr int kRowBytes = 2 * kM * (int)sizeof(double2), kStepBytes = 2 * L * kRowBytes;
+    const __amdgpu_buffer_rsrc_t bk_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(bkf1), (short)0, K.n * kStepBytes, 0x00020000);
+    const int lane16 = lane * (int)sizeof(double2);
+    const unsigned char* accb = reinterpret_cast<const unsigned char*>(acc);  // LDS offset 0 of the workgroup
+    const uint32_t pb = (uint32_t)wave * (kN * 4);                             // this wave's polynomial
+    const int32_t* accp = acc + wave * kN;
+    uint32_t* accu = reinterpret_cast<uint32_t*>(acc) + wave * kN;
+
+    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
+        if (a == 0) continue;  // workgroup-uniform
+        const int bki = i * kStepBytes + wave * L * kRowBytes;  // this wave's rows of BK_i
+        double2 s[2][8];
+        uint32_t v0[8], v1[8];
+        const uint32_t jb4 = ((uint32_t)(lane - a) & (2 * kN - 1)) << 2;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t t = jb4 + 256u * r;
+            const uint32_t o0 = (t & 4092u) | pb, o1 = o0 ^ 2048u;
+            const int32_t m0 = __builtin_amdgcn_sbfe((int32_t)t, 12, 1), m1 = __builtin_amdgcn_sbfe((int32_t)(t + 2048u), 12, 1);
+            const uint32_t rv0 = *reinterpret_cast<const uint32_t*>(accb + o0), rv1 = *reinterpret_cast<const uint32_t*>(accb + o1);
+            const uint32_t pv0 = (uint32_t)accp[64 * r + lane], pv1 = (uint32_t)accp[64 * r + lane + kM];
+            v0[r] = ((rv0 ^ (uint32_t)m0) + ((dec_offset - pv0) - (uint32_t)m0)) ^ dec_offset;
+            v1[r] = ((rv1 ^ (uint32_t)m1) + ((dec_offset - pv1) - (uint32_t)m1)) ^ dec_offset;
+        }
+        auto digit_row = [&](const int sh, const int brow, auto first) {
+            constexpr bool FIRST = decltype(first)::value;
+            double2 x[8], bA[8], bB[8];
+            load_bk_block<true>(bA, bk_rsrc, lane16, brow, bkf1);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);
+                const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
+                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft512_forward<true, 1, 0>(x, sT, lane, R);
+            load_bk_block<true>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[0][k] = FIRST ? cmulx<false>(x[k], bA[k])
+                                : make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[0][k].x)),
+                                               fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[0][k].y)));
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[1][k] = FIRST ? cmulx<false>(x[k], bB[k])
+                                : make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
+                                               fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
+        };
+        digit_row(32 - BGBIT, bki, std::true_type{});
+#pragma unroll 1
+        for (int q = 1; q < L; q++) digit_row(32 - (q + 1) * BGBIT, bki + q * kRowBytes, std::false_type{});
+        // the partial sum of the partner's output goes to the partner through this wave's tile (idle since the last transform)
+        double2 y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double2 mine = wave ? s[1][k] : s[0][k], theirs = wave ? s[0][k] : s[1][k];
+            sT[k * 64 + lane] = theirs;
+            y[k] = mine;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double2 z = sTp[k * 64 + lane];
+            y[k] = cadd(y[k], z);
+        }
+        __syncthreads();  // the partner has read this wave's tile before the inverse transform reuses it
+        fft512_inverse<true, 0>(y, sT, lane, R);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
+            double t0, t1;
+            if (r == 0) {
+                if (watched) {
+                    const double zx = y[0].x * (1.0 / 512.0), zy = y[0].y * (1.0 / 512.0);
+                    t0 = zx + kMagic, t1 = zy + kMagic;
+                    dev_max = fmax(dev_max, fabs(zx - (t0 - kMagic)));
+                    dev_max = fmax(dev_max, fabs(zy - (t1 - kMagic)));
+                } else {
+                    t0 = fma(y[0].x, 1.0 / 512.0, kMagic), t1 = fma(y[0].y, 1.0 / 512.0, kMagic);
+                }
+            } else {
+                const double2 z = cmulx<true>(y[r], untwist_reg(r));
+                t0 = z.x + kMagic, t1 = z.y + kMagic;
+                if (watched) {
+                    dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
+                    dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
+                }
+            }
+            const int32_t j = 64 * r + lane;
+            __hip_atomic_fetch_add(&accu[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&accu[j + kM], (uint32_t)__double2loint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        wave_sync();  // wave w reads and updates only polynomial w: nothing crosses waves here
+    }
+    __syncthreads();  // the epilogue below reads both polynomials with all threads
+    if (GUARD) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
+        }
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = tid; j <= kN; j += 128)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[128 * r + tid] = src[128 * r + tid];
+    }
+}
+
 // ---- K3 (+K4), mid-size launches: two waves per gate instance on the ONE-limb spectrum ----
 // Between the latency kernel (a handful of gates) and k_blind_rotate_w1 (more gates than the chip holds one-per-SIMD-slot)
 // lie launches of a few hundred to ~1 000 gates: deep circuits at small batches, cloudd's batches.  One wave per gate
@@ -1225,6 +1573,152 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
 }
 
 
+// ---- K3 (+K4), latency-oriented, round 3: 2L waves per gate, FOUR output waves on half the rows each ----
+// k_blind_rotate_wide on the one-limb spectrum leaves the six row products and the inverse transform of an output
+// polynomial to ONE wave (two output waves; the other four idle for half of the step), and its tiles serve both as the
+// published spectra and as the inverse transforms' scratch (barrier B).  Here waves 0..3 are output waves (one per SIMD):
+// output wave (c, h) = (w & 1, w >> 1) multiplies the L published spectra of accumulator polynomial h with block c of
+// their BK rows -- its L blocks are requested at the top of the step and arrive under the decomposition and the forward
+// transform --, inverse-transforms that PARTIAL sum in a scratch tile of its own (no barrier B), rounds it and adds it
+// into accumulator polynomial c with ds_add_u32.  Each partial sum is an integer polynomial and addition mod 2^32
+// commutes, so the two halves of an output need no ordering.  Two barriers per step (spectra published / accumulator
+// updated).  Same rounded integers as every other kernel here.
+// dynamic LDS: acc [2][1024] int32 | sT [2L + 4][kTile] double2 | tw [kTwElems] double2 | bara [i1-i0] u16
+template <int L, int BGBIT, int GUARD>
+__global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const double2* __restrict__ bkf1,
+                                                              const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                              int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
+                                                              unsigned* guard, const double2* __restrict__ gtw) {
+    constexpr int NW = 2 * L, NT = 64 * NW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    int32_t* acc = reinterpret_cast<int32_t*>(smem);
+    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)2 * kN * 4);
+    double2* sTw = sT_all + (NW + 4) * kTile;
+    uint16_t* s_bara = reinterpret_cast<uint16_t*>(sTw + kTwElems);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;                  // forward scratch, then this wave's published spectrum
+    double2* sTi = sT_all + (NW + (wave & 3)) * kTile;    // inverse scratch of output wave `wave`
+    const int64_t item = (int64_t)blockIdx.x;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    load_twiddles(sTw, gtw, tid, NT);
+    const LaneRoots R = make_roots(sTw, lane);
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+        for (int idx = tid; idx < 2 * kN / 4; idx += NT) dst[idx] = src[idx];
+        const uint16_t* bara = st_bara + (size_t)item * nb;
+        for (int idx = tid; idx < i1 - i0; idx += NT) s_bara[idx] = bara[i0 + idx];
+    }
+    __syncthreads();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;
+    const int pw = wave / L, qw = wave - pw * L;  // forward role: digit qw of polynomial pw = row `wave` of BK_i
+    const int sh = 32 - (qw + 1) * BGBIT;
+    const bool is_out = wave < 4;
+    const int oc = wave & 1, oh = (wave >> 1) & 1;  // output role: block oc of the rows of polynomial oh
+    uint32_t* acco = reinterpret_cast<uint32_t*>(acc) + oc * kN;
+    const unsigned char* accb = reinterpret_cast<const unsigned char*>(acc);
+    const uint32_t pb = (uint32_t)pw * (kN * 4);
+    const int32_t* accp = acc + pw * kN;
+    double dev_max = 0.0;
+
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readfirstlane((int32_t)s_bara[i - i0]);
+        if (a == 0) continue;  // workgroup-uniform
+        // BK_i rows [2L][2][8][64]: this output wave's L blocks, all requested now
+        const double2* __restrict__ bki = bkf1 + (size_t)i * (2 * L * 2 * kM) + (size_t)(oh * L) * (2 * kM) + (size_t)oc * kM + lane;
+        double2 bk[L][8];
+        if (is_out) {
+#pragma unroll
+            for (int q = 0; q < L; q++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) bk[q][k] = bki[(size_t)q * (2 * kM) + k * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int32_t lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // opaque: keeps the per-coefficient LDS addresses from being hoisted out of the step loop
+        const uint32_t jb4 = ((uint32_t)(lane_o - a) & (2 * kN - 1)) << 2;
+        uint32_t rv0[8], rv1[8], pv0[8], pv1[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {   // all 32 LDS reads first, then the arithmetic
+            const uint32_t t = jb4 + 256u * r;
+            const uint32_t o0 = (t & 4092u) | pb, o1 = o0 ^ 2048u;
+            rv0[r] = *reinterpret_cast<const uint32_t*>(accb + o0);
+            rv1[r] = *reinterpret_cast<const uint32_t*>(accb + o1);
+            pv0[r] = (uint32_t)accp[64 * r + lane_o];
+            pv1[r] = (uint32_t)accp[64 * r + lane_o + kM];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t t = jb4 + 256u * r;
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)t, 12, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(t + 2048u), 12, 1);
+            const uint32_t u0 = (rv0[r] ^ m0) + ((dec_offset - pv0[r]) - m0);
+            const uint32_t u1 = (rv1[r] ^ m1) + ((dec_offset - pv1[r]) - m1);
+            // digit - halfBg = sign-extended field of (u ^ (halfBg << sh))
+            const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)(u0 ^ (halfBg << sh)), sh, BGBIT);
+            const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
+            x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                          : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+        }
+        fft512_forward<true, 0>(x, sT, lane, R);
+#pragma unroll
+        for (int k = 0; k < 8; k++) sT[k * 64 + lane] = x[k];  // publish
+        __syncthreads();  // A: all 2L spectra are in their tiles
+        if (is_out) {
+            double2 s[8];
+#pragma unroll
+            for (int q = 0; q < L; q++) {
+                const double2* sp = sT_all + (oh * L + q) * kTile + lane;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const double2 y = sp[k * 64];
+                    s[k] = q == 0 ? cmulx<false>(y, bk[0][k])
+                                  : make_double2(fma(y.x, bk[q][k].x, fma(-y.y, bk[q][k].y, s[k].x)), fma(y.x, bk[q][k].y, fma(y.y, bk[q][k].x, s[k].y)));
+                }
+            }
+            fft512_inverse<true, 0>(s, sTi, lane, R);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
+                const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
+                const double t0 = z.x + kMagic, t1 = z.y + kMagic;
+                if (watched) dev_max = fmax(dev_max, fmax(fabs(z.x - (t0 - kMagic)), fabs(z.y - (t1 - kMagic))));
+                const int32_t j = 64 * r + lane;
+                atomicAdd(&acco[j], (uint32_t)__double2loint(t0));  // ds_add_u32; the other half of this output adds to the same word
+                atomicAdd(&acco[j + kM], (uint32_t)__double2loint(t1));
+            }
+        }
+        __syncthreads();  // C: accumulator complete before the next decomposition; every published spectrum consumed
+    }
+    if (GUARD && is_out) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
+        }
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = tid; j <= kN; j += NT)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+        for (int idx = tid; idx < 2 * kN / 4; idx += NT) dst[idx] = src[idx];
+    }
+}
+
 // ---- K3 (+K4), latency-oriented on the ONE-limb spectrum: 2L waves per gate, every wave a whole row ----
 // k_blind_rotate_wide hands all 2L spectra to four output waves (two barriers, 192 KiB of LDS reads, 192 KiB of BK through
 // one CU per step).  The inverse transform is linear and every row's product digit_row (*) BK_row is itself an integer
@@ -1538,6 +2032,44 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
             hipLaunchKernelGGL((k_blind_rotate_w2s<L, BGBIT, false>), g2, b2, lds2, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
         return;
     }
+#define IEACHE_W1B(...)                                                                                                         \
+    {                                                                                                                           \
+        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_w1b<L, BGBIT, __VA_ARGS__>,                \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_w1()) == hipSuccess; \
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_w1b"); \
+        hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
+                           st_acc, items, i0, i1, e, guard, gtw);                                                               \
+    }
+    if (sub == 25 || sub == 26) {  // round 3: latency kernel with four output waves on half the rows each; 26 = guard on every coefficient
+        const size_t lds_w4 = (size_t)((2 * L + 4) * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
+        static const bool attr_set =
+            hipFuncSetAttribute((const void*)k_blind_rotate_wide4<L, BGBIT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+            hipFuncSetAttribute((const void*)k_blind_rotate_wide4<L, BGBIT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide4");
+        if (sub == 25)
+            hipLaunchKernelGGL((k_blind_rotate_wide4<L, BGBIT, 2>), dim3((unsigned)items), dim3(128 * L), lds_w4, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
+        else
+            hipLaunchKernelGGL((k_blind_rotate_wide4<L, BGBIT, 1>), dim3((unsigned)items), dim3(128 * L), lds_w4, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
+        return;
+    }
+    if (sub == 23 || sub == 24) {  // round 3: two waves per gate, rows split (mid-size launches); 24 = guard on every coefficient
+        const dim3 g2((unsigned)items), b2(128);
+        const size_t lds2 = (size_t)(2 * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
+        if (sub == 23)
+            hipLaunchKernelGGL((k_blind_rotate_w2r<L, BGBIT, 2>), g2, b2, lds2, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
+        else
+            hipLaunchKernelGGL((k_blind_rotate_w2r<L, BGBIT, 1>), g2, b2, lds2, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
+        return;
+    }
+    switch (sub) {  // round 3: k_blind_rotate_w1b
+        case 18: IEACHE_W1B(2, 0) return;   // guard on one coefficient in four
+        case 19: IEACHE_W1B(1, 0) return;   // guard on every coefficient
+        case 20: IEACHE_W1B(2, 1) return;   // polynomial 1's forward transposes through LDS
+        case 21: IEACHE_W1B(2, 2) return;   // every second row's
+        case 22: IEACHE_W1B(0, 0) return;   // no guard arithmetic (measurement)
+        default: break;
+    }
+#undef IEACHE_W1B
     switch (sub) {  // > 64 KiB of dynamic LDS has to be allowed explicitly, per instantiation
         case 1: IEACHE_W1(false) break;          // no guard arithmetic (measurement)
         case 2: IEACHE_W1(true, 0) break;        // forward transposes through LDS
@@ -1564,7 +2096,7 @@ int32_t default_slice() {
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
-    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 17;
+    const bool one_limb = variant >= kVariantOneLimb && variant <= kVariantOneLimb + 40;
     if (one_limb && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
     const dim3 grid((unsigned)items), blk(128);
@@ -1579,7 +2111,8 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     hipLaunchKernelGGL(k_br_prologue, grid, blk, 0, stream, K, W, st_bara, nb, st_acc);
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
-    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || (variant >= kVariantWideOneLimb && variant <= kVariantWideOneLimb + 7)) ? nb : 64;
+    const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || (variant >= kVariantWideOneLimb && variant <= kVariantWideOneLimb + 7) ||
+                               variant == kVariantOneLimb + 25 || variant == kVariantOneLimb + 26) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;

@@ -276,6 +276,12 @@ int ieache_ctx_fft_guard(const ieache_ctx* ctx, double* max_deviation, int64_t* 
     return 0;
 }
 
+int ieache_ctx_fft_audit(const ieache_ctx* ctx, int64_t* audits, int64_t* gates_compared, int64_t* mismatches) {
+    if (!ctx) return fail(IEACHE_EINVAL, "null context");
+    ctx->eval->fft_audit_counts(audits, gates_compared, mismatches);
+    return 0;
+}
+
 const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx) {
     if (!ctx) return "";
     const_cast<ieache_ctx*>(ctx)->variant = ctx->eval->kernel_variant();

@@ -428,30 +428,64 @@ void decode(const std::string& path, const std::vector<Layout>& candidates, cons
     const Layout* chosen = nullptr;
     size_t size_matches = 0;
     std::string why;
+    std::vector<const Layout*> passing;
+    auto plausible_variance = [&](size_t at) {
+        // a variance is -1 (libtfhe's "unset"), 0, or a small positive number.  Eight bytes of uniformly random key
+        // material pass this with probability ~1/4 (sign bit clear and exponent below 1023), and eight ZERO bytes -- the
+        // head of a key-switch key that carries its d = 0 rows -- always do, so a single field proves little: the
+        // structural checks below (every per-sample variance, all-zero d = 0 rows) and the uniqueness test after the
+        // loop are what separate layouts of equal size that differ only in where the doubles stand.
+        double v;
+        bin.read(at, 8, &v);
+        return v == -1.0 || (v >= 0.0 && v < 1.0);
+    };
     for (const Layout& L : candidates) {
         if (L.bytes(p) != bin.total) continue;
         size_matches++;
         bool ok = true;
         size_t pos = 0;
+        auto reject = [&](const std::string& msg) {
+            if (why.empty()) why = msg;
+            ok = false;
+        };
         for (const Field& f : L.fields) {
             if (f.kind == F_UID && bin.i32(pos) != f.uid) {
-                if (why.empty()) why = "expected " + f.name + " " + std::to_string(f.uid) + ", found " + std::to_string(bin.i32(pos));
-                ok = false;
+                reject("expected " + f.name + " " + std::to_string(f.uid) + ", found " + std::to_string(bin.i32(pos)));
                 break;
             }
-            if (f.kind == F_VAR || ((f.kind == F_KSK || f.kind == F_BK) && f.sample_var)) {
-                // a variance is -1 (libtfhe's "unset"), 0, or a small positive number; 8 bytes of key
-                // material pass this with probability ~2 %, which separates layouts of equal size
-                // that differ only in where the doubles stand
-                const size_t at = f.kind == F_VAR ? pos
-                                  : pos + (f.kind == F_KSK ? (size_t)(p.n + 1) * 4 : (size_t)(p.k + 1) * p.N * 4);
-                double v;
-                bin.read(at, 8, &v);
-                if (!(v == -1.0 || (v >= 0.0 && v < 1.0))) {
-                    if (why.empty()) why = "a variance field holds an implausible value";
-                    ok = false;
-                    break;
+            if (f.kind == F_VAR && !plausible_variance(pos)) {
+                reject("a variance field holds an implausible value");
+                break;
+            }
+            if (f.kind == F_KSK) {
+                const size_t S4 = (size_t)(p.n + 1) * 4, rec = S4 + (f.sample_var ? 8 : 0);
+                const size_t base = (size_t)p.ks_base(), per_ij = f.skip_d0 ? base - 1 : base;
+                const size_t n_ij = (size_t)p.k * p.N * p.ks_t;
+                // 256 positions spread over the whole array (all of it when it is that small)
+                const size_t stride_ij = n_ij > 256 ? n_ij / 256 : 1;
+                std::vector<int32_t> row((size_t)p.n + 1);
+                for (size_t ij = 0; ij < n_ij && ok; ij += stride_ij) {
+                    const size_t at = pos + ij * per_ij * rec;
+                    if (!f.skip_d0) {  // KS[i][j][0] encrypts 0 without noise: an all-zero sample (lweNoiselessTrivial)
+                        bin.read(at, S4, row.data());
+                        for (int32_t v : row)
+                            if (v != 0) {
+                                reject("a d = 0 row of the key-switch key is not zero");
+                                break;
+                            }
+                    }
+                    if (f.sample_var && ok)
+                        for (size_t d = 0; d < per_ij && ok; d++)
+                            if (!plausible_variance(at + d * rec + S4)) reject("a per-sample variance of the key-switch key holds an implausible value");
                 }
+                if (!ok) break;
+            }
+            if (f.kind == F_BK && f.sample_var) {
+                const size_t row4 = (size_t)(p.k + 1) * p.N * 4, rows = (size_t)p.n * p.kpl();
+                const size_t stride_r = rows > 512 ? rows / 512 : 1;
+                for (size_t r = 0; r < rows && ok; r += stride_r)
+                    if (!plausible_variance(pos + r * (row4 + 8) + row4)) reject("a per-row variance of the bootstrapping key holds an implausible value");
+                if (!ok) break;
             }
             if (f.kind == F_LWEKEY || f.kind == F_TGSWKEY) {  // secret keys are bits
                 const size_t cnt = Layout::field_bytes(f, p) / 4;
@@ -466,11 +500,39 @@ void decode(const std::string& path, const std::vector<Layout>& candidates, cons
             }
             pos += Layout::field_bytes(f, p);
         }
-        if (ok) {
-            chosen = &L;
-            break;  // candidates are ordered by preference (this build's writer first)
+        if (ok) passing.push_back(&L);
+    }
+    if (passing.size() > 1) {
+        // Two layouts of the same size both look sound: decoding the wrong one would shift the key material by a few
+        // bytes without any error.  This build's own writer (the first candidate) is identified by its two type tags
+        // at fixed places; anything else is refused rather than guessed.
+        bool own = passing[0] == &candidates[0];
+        if (!own) {
+            // hypotheses that place the key-switch key and the bootstrapping key identically differ only in the order of
+            // two untagged secret-key arrays, where libtfhe's order (LWE key, then TGSW key) is the documented preference
+            auto placement = [&](const Layout& L) {
+                std::vector<size_t> v;
+                size_t pos = 0;
+                for (const Field& f : L.fields) {
+                    if (f.kind == F_KSK || f.kind == F_BK) {
+                        v.push_back(pos);
+                        v.push_back((size_t)f.kind * 4 + (f.skip_d0 ? 2 : 0) + (f.sample_var ? 1 : 0));
+                    }
+                    pos += Layout::field_bytes(f, p);
+                }
+                return v;
+            };
+            const std::vector<size_t> first = placement(*passing[0]);
+            own = true;
+            for (const Layout* L : passing) own = own && placement(*L) == first;
+        }
+        if (!own) {
+            std::string msg = path + ": ambiguous key layout: " + std::to_string(passing.size()) + " hypotheses fit the size, the tags and the structural checks (";
+            for (size_t q = 0; q < passing.size() && q < 3; q++) msg += (q ? " | " : "") + passing[q]->desc;
+            throw CodecError(msg + (passing.size() > 3 ? " | ...)" : ")"));
         }
     }
+    if (!passing.empty()) chosen = passing[0];  // candidates are ordered by preference (this build's writer first)
     if (!chosen) {
         char buf[256];
         snprintf(buf, sizeof buf, "%s: no key layout fits: %zu binary bytes for n=%d N=%d k=%d l=%d t=%d basebit=%d (%zu of %zu hypotheses match the size%s%s)",

@@ -89,7 +89,8 @@ public:
     // "exact_fft" (1 = two-limb blind rotation always), "one_limb_min" (launches of at least this many gate
     // instances use the one-limb kernels; default: one per CU + 1), "two_wave_max" (of those, launches up to this many
     // gate instances take two waves per gate, k_blind_rotate_w2s; default 4 per CU), "fft_guard_inject" (test hook: 1 makes
-    // the next call find the rounding guard tripped, so that it repeats itself on the two-limb kernels).
+    // the next call find the rounding guard tripped, so that it repeats itself on the two-limb kernels), "fft_audit" (see
+    // fft_audit_counts), "fft_audit_inject" (test hook: 1 makes the next audit report a differing row).
     // Returns false for an unknown name or a value out of range.
     bool set_option(const std::string& name, int64_t value);
     std::string kernel_variant() const;
@@ -100,6 +101,11 @@ public:
     double fft_guard_max() const;
     int64_t fft_guard_reruns() const;
     bool fft_guard_tripped();  // internal: reads and re-arms the device-side record
+    // The sampled audit behind the guard (option "fft_audit" = K, default 64, 0 = off; IEACHE_FFT_AUDIT): every K-th launch
+    // that took a one-limb kernel has 64 of its gate instances run again on the two-limb kernel and compared word for word;
+    // a differing row makes the call repeat itself on the two-limb kernels (counted in fft_guard_reruns()).
+    // -> audits run, gate instances compared, rows that differed, over the context's life.
+    void fft_audit_counts(int64_t* audits, int64_t* gates, int64_t* mismatches) const;
 
     struct Impl;  // device buffers; defined in evaluator.hip
 

@@ -480,6 +480,18 @@ __global__ void k_mux_combine(const Torus32* ext, Torus32* dst, int32_t N) {
         d[j] = (int32_t)((uint32_t)u1[j] + (uint32_t)u2[j] + (j == N ? (uint32_t)kMU : 0u));
 }
 
+// Audit of the one-limb blind rotation: rows of extracted samples it produced against the same gate instances run on the
+// two-limb (provably exact) kernel.  One workgroup per row; any differing word counts the row in *mismatches.
+// inject: test hook -- row 0 is compared as if its first word differed.
+__global__ void k_audit_compare(const Torus32* primary, const Torus32* exact, int32_t N, unsigned* mismatches, int inject) {
+    const size_t g = blockIdx.x;
+    const Torus32* a = primary + g * (size_t)(N + 4);
+    const Torus32* b = exact + g * (size_t)(N + 4);
+    int bad = (inject && g == 0 && threadIdx.x == 0) ? 1 : 0;
+    for (int32_t j = threadIdx.x; j <= N; j += blockDim.x) bad |= a[j] != b[j];
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicAdd(mismatches, 1u);
+}
+
 // outputs of a circuit: out[b][o] = +-store[b][slot] or the constant
 __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus32* store, int32_t n_slots,
                                  Torus32* out, int64_t batch, int32_t stride, int32_t n) {
@@ -508,13 +520,21 @@ struct Evaluator::Impl {
     double2* bkf_w64 = nullptr;  // spectrum in the wave-per-gate kernel's layout
     double2* tw_w64 = nullptr;   // its twiddle table
     double2* bkf1_w64 = nullptr; // one-limb spectrum of k_blind_rotate_w1
-    unsigned* fft_guard = nullptr;  // [0] launches whose rounding deviation exceeded the limit, [1] max deviation (float bits)
+    unsigned* fft_guard = nullptr;  // [0] launches whose rounding deviation exceeded the limit, [1] max deviation (float bits), [2] audit rows that differed
     bool exact_fft = false;      // "exact_fft": never use the one-limb kernel
     bool exact_once = false;     // set while a call is repeated after a guard trip
     int64_t one_limb_min = 0;    // launches of at least this many gate instances use the one-limb kernels
     int64_t two_wave_max = 0;    // ... the two-waves-per-gate one up to this many (4 per CU: all resident at once), the one-wave one above
     double guard_max = 0;        // largest rounding deviation seen by the one-limb kernel (of 0.5)
     int64_t guard_reruns = 0;    // calls repeated on the two-limb kernel
+    // "fft_audit" = K: every K-th (level, chunk) launch that took a one-limb kernel has a sample of kAuditGates of its gate
+    // instances run again on the two-limb kernel and compared word for word (fft_guard[2] counts differing rows); 0 = off
+    int32_t fft_audit = 64;
+    int64_t audit_seq = 0;       // one-limb (level, chunk) launches so far
+    int64_t audits = 0, audit_gates = 0, audit_mismatches = 0;
+    bool audit_inject = false;   // test hook: the next audit reports a mismatch
+    Torus32* audit_ext = nullptr;
+    void* audit_state = nullptr;
     int cus = 0;
     bool use_w64 = false;
     bool force_generic_ks = false;
@@ -582,6 +602,7 @@ void Evaluator::init() {
         if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
         if (const char* e = getenv("IEACHE_ONE_LIMB_MIN")) d_->one_limb_min = atoll(e);
         if (const char* e = getenv("IEACHE_EXACT_FFT")) d_->exact_fft = atoi(e) != 0;
+        if (const char* e = getenv("IEACHE_FFT_AUDIT")) d_->fft_audit = atoi(e) > 0 ? atoi(e) : 0;
         if (!w64::one_limb_supported(p)) d_->exact_fft = true;
         resident_two_wave_ = 4 * cus;
         if (d_->exact_fft) {
@@ -654,6 +675,8 @@ void Evaluator::destroy() {
     (void)hipFree(d_->tw_w64);
     (void)hipFree(d_->bkf1_w64);
     (void)hipFree(d_->fft_guard);
+    (void)hipFree(d_->audit_ext);
+    (void)hipFree(d_->audit_state);
     (void)hipFree(d_->ksk);
     (void)hipFree(d_->twist);
     (void)hipFree(d_->wtab);
@@ -703,7 +726,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 1 && value <= 4096) {
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 30) {
+    } else if (name == "br_variant" && value >= 0 && value <= 60) {
         d_->br_variant = (int32_t)value;
     } else if (name == "exact_fft" && (value == 1 || (value == 0 && w64::one_limb_supported(p_)))) {
         d_->exact_fft = value != 0;
@@ -714,6 +737,10 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
     } else if (name == "two_wave_max" && value >= 0) {
         d_->two_wave_max = value;
 
+    } else if (name == "fft_audit" && value >= 0 && value <= (1 << 30)) {
+        d_->fft_audit = (int32_t)value;
+    } else if (name == "fft_audit_inject" && value == 1) {
+        d_->audit_inject = true;
     } else if (name == "fft_guard_inject" && value == 1 && d_->fft_guard) {
         // test hook: the next call finds the guard tripped and repeats itself on the two-limb kernel
         const unsigned one = 1;
@@ -776,8 +803,8 @@ void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
         HIP_CHECK(hipGetLastError());
         if (!d_->bkf1_w64) HIP_CHECK(hipMalloc(&d_->bkf1_w64, w64::spectrum1_elems(p_) * sizeof(double2)));
         if (!d_->fft_guard) {
-            HIP_CHECK(hipMalloc(&d_->fft_guard, 2 * sizeof(unsigned)));
-            HIP_CHECK(hipMemsetAsync(d_->fft_guard, 0, 2 * sizeof(unsigned), stream_));
+            HIP_CHECK(hipMalloc(&d_->fft_guard, 4 * sizeof(unsigned)));
+            HIP_CHECK(hipMemsetAsync(d_->fft_guard, 0, 4 * sizeof(unsigned), stream_));
         }
         w64::prepare_spectrum1(p_, d_bk, d_->bkf1_w64, stream_);
         HIP_CHECK(hipGetLastError());
@@ -817,6 +844,27 @@ struct Timer {
 };
 }  // namespace
 
+// Which blind-rotation kernel a launch of `cnt` gate instances takes (br_variant 0 = by launch size: the 2L-waves-per-gate
+// kernel for a handful of gates, two waves per gate on the one-limb spectrum while every gate is resident at once, one wave
+// per gate above; "exact_fft" / a repeat after a guard trip: the two-limb kernels).
+static void pick_br_variant(const Params& p, const Evaluator::Impl* d, int64_t cnt, int32_t* variant_out, int32_t* slice_out) {
+    int32_t variant = d->br_variant, slice = d->br_slice;
+    if (variant == 0) {
+        if (cnt <= d->br_wide_max) {
+            // the latency kernel, on the one-limb spectrum unless exactness by construction is asked for
+            variant = (d->exact_fft || d->exact_once) ? w64::kVariantWide : w64::kVariantWideHandoverOneLimb;
+            slice = w64::bara_stride(p);
+        } else if (!d->exact_fft && !d->exact_once && cnt >= d->one_limb_min) {
+            // while every gate fits a two-wave slot, two waves per gate finish a step sooner than one
+            variant = cnt <= d->two_wave_max ? w64::kVariantOneLimbTwoWaves : w64::kVariantOneLimbDefault;
+        }
+    } else if (d->exact_once && variant >= w64::kVariantOneLimb) {
+        variant = 0;
+    }
+    *variant_out = variant;
+    *slice_out = slice;
+}
+
 // Runs `items` gate instances described by W (item0 is advanced per chunk).
 static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt,
                                 Torus32* ext, int32_t steps, Torus32* dbg_acc) {
@@ -828,21 +876,8 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
             HIP_CHECK(hipMalloc(&d->br_state, items * w64::state_bytes_per_item(p)));
             d->br_state_items = items;
         }
-        // br_variant 0 = by launch size: the 2L-waves-per-gate kernel for a handful of gates, the two-wave two-limb kernel while
-        // every gate is resident at once, the one-wave one-limb kernel (guarded) for wide launches
-        int32_t variant = d->br_variant, slice = d->br_slice;
-        if (variant == 0) {
-            if (cnt <= d->br_wide_max) {
-                // the latency kernel, on the one-limb spectrum unless exactness by construction is asked for
-                variant = (d->exact_fft || d->exact_once) ? w64::kVariantWide : w64::kVariantWideHandoverOneLimb;
-                slice = w64::bara_stride(p);
-            } else if (!d->exact_fft && !d->exact_once && cnt >= d->one_limb_min) {
-                // while every gate fits a two-wave slot, two waves per gate finish a step sooner than one
-                variant = cnt <= d->two_wave_max ? w64::kVariantOneLimbTwoWaves : w64::kVariantOneLimb;
-            }
-        } else if (d->exact_once && variant >= w64::kVariantOneLimb) {
-            variant = 0;
-        }
+        int32_t variant, slice;
+        pick_br_variant(p, d, cnt, &variant, &slice);
         return w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, w, cnt, d->br_state, ext, steps, dbg_acc, slice, variant,
                            d->tw_w64, stream);
     }
@@ -850,6 +885,35 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
         hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,
                            steps, dbg_acc);
     return 1;
+}
+
+// The sampled audit behind the rounding guard: after a (level, chunk) launch that took a one-limb kernel, every
+// fft_audit-th time, kAuditGates consecutive gate instances of it (at an offset that moves from audit to audit) are run
+// again on the two-limb kernel -- exact by construction -- and their extracted samples compared word for word with what the
+// one-limb kernel wrote to `ext`.  A differing row is counted on the device; the call then repeats itself on the
+// two-limb kernels like a call whose guard tripped (Evaluator::fft_guard_tripped).  The guard watches the error LEVEL of
+// every launch; this compares BITS, of a sample.
+constexpr int64_t kAuditGates = 64;
+static void maybe_audit(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt, const Torus32* ext) {
+    if (!d->use_w64 || d->fft_audit <= 0 || !d->fft_guard) return;
+    int32_t variant, slice;
+    pick_br_variant(p, d, cnt, &variant, &slice);
+    if (variant < w64::kVariantOneLimb) return;  // the launch was exact by construction
+    if (++d->audit_seq % d->fft_audit != 0) return;
+    const int64_t m = std::min<int64_t>(kAuditGates, cnt);
+    const int64_t off = cnt > m ? (int64_t)(((uint64_t)d->audit_seq * 0x9E3779B97F4A7C15ull >> 33) % (uint64_t)(cnt - m + 1)) : 0;
+    if (!d->audit_ext) HIP_CHECK(hipMalloc(&d->audit_ext, (size_t)kAuditGates * (size_t)(d->K.N + 4) * 4));
+    if (!d->audit_state) HIP_CHECK(hipMalloc(&d->audit_state, (size_t)kAuditGates * w64::state_bytes_per_item(p)));
+    WorkDesc wa = w;
+    wa.item0 = w.item0 + off;
+    w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, wa, m, d->audit_state, d->audit_ext, -1, nullptr, w64::bara_stride(p),
+                w64::kVariantWide, d->tw_w64, stream);
+    hipLaunchKernelGGL(k_audit_compare, dim3((unsigned)m), dim3(256), 0, stream, ext + (size_t)off * (size_t)(d->K.N + 4), d->audit_ext,
+                       d->K.N, d->fft_guard + 2, d->audit_inject ? 1 : 0);
+    HIP_CHECK(hipGetLastError());
+    d->audit_inject = false;
+    d->audits++;
+    d->audit_gates += m;
 }
 
 static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt, const Torus32* ext,
@@ -903,6 +967,7 @@ static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, W
         const int nbr = launch_blind_rotate(p, d, stream, w, cnt, d->ext, -1, nullptr);
         tbr.mark();
         HIP_CHECK(hipGetLastError());
+        maybe_audit(p, d, stream, w, cnt, d->ext);
         tks.mark();
         launch_keyswitch(d, stream, w, cnt, d->ext, nullptr, d->force_generic_ks);
         tks.mark();
@@ -920,14 +985,23 @@ static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, W
 // repeated on the two-limb kernel (some launch saw a coefficient further than kGuardLimit from an integer).
 bool Evaluator::fft_guard_tripped() {
     if (!d_->fft_guard) return false;
-    unsigned h[2] = {0, 0};
+    unsigned h[3] = {0, 0, 0};
     HIP_CHECK(hipMemcpy(h, d_->fft_guard, sizeof h, hipMemcpyDeviceToHost));
     float m;
     memcpy(&m, &h[1], sizeof m);
     if ((double)m > d_->guard_max) d_->guard_max = (double)m;
-    if (h[0] == 0) return false;
-    HIP_CHECK(hipMemset(d_->fft_guard, 0, sizeof(unsigned)));  // the count only; the maximum stays
+    if (h[0] == 0 && h[2] == 0) return false;
+    d_->audit_mismatches += h[2];
+    // the two counts only; the maximum stays
+    HIP_CHECK(hipMemset(d_->fft_guard, 0, sizeof(unsigned)));
+    HIP_CHECK(hipMemset(d_->fft_guard + 2, 0, sizeof(unsigned)));
     return true;
+}
+
+void Evaluator::fft_audit_counts(int64_t* audits, int64_t* gates, int64_t* mismatches) const {
+    if (audits) *audits = d_->audits;
+    if (gates) *gates = d_->audit_gates;
+    if (mismatches) *mismatches = d_->audit_mismatches;
 }
 
 double Evaluator::fft_guard_max() const { return d_->guard_max; }
@@ -937,14 +1011,26 @@ namespace {
 bool overlaps(const Torus32* a, size_t na, const Torus32* b, size_t nb) {
     return a && b && a < b + nb && b < a + na;
 }
-// Repeats `once` on the two-limb kernel when the guard tripped; the first attempt's time stays in the stats, its counts do not.
+// Repeats `once` on the two-limb kernels when the guard tripped or an audited row differed; the first attempt's time stays
+// in the stats, its counts do not.  A call whose output overlaps its inputs cannot be repeated (the first attempt has
+// overwritten them), so it runs on the two-limb kernels -- exact by construction -- from the start.
 template <class F>
 void run_guarded(Evaluator& ev, bool* exact_once, int64_t* reruns, bool inputs_intact, EvalStats* stats, F&& once) {
+    if (!inputs_intact && !*exact_once) {
+        *exact_once = true;
+        try {
+            once();
+        } catch (...) {
+            *exact_once = false;
+            throw;
+        }
+        *exact_once = false;
+        (void)ev.fft_guard_tripped();  // folds the record of earlier calls; nothing this call did can trip it
+        return;
+    }
     const EvalStats before = stats ? *stats : EvalStats{};
     once();
     if (!ev.fft_guard_tripped()) return;
-    if (!inputs_intact)
-        throw std::runtime_error("FFT rounding guard tripped and the output overlaps the inputs: repeat the call with option exact_fft=1");
     (*reruns)++;
     EvalStats first{};
     if (stats) {
@@ -1054,6 +1140,7 @@ void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32*
         const int nbr = launch_blind_rotate(p_, d_, stream_, W, 2 * cnt, d_->ext, -1, nullptr);
         tbr.mark();
         HIP_CHECK(hipGetLastError());
+        maybe_audit(p_, d_, stream_, W, 2 * cnt, d_->ext);
         tks.mark();
         hipLaunchKernelGGL(k_mux_combine, dim3((unsigned)cnt), dim3(256), 0, stream_, d_->ext, d_->ext_mux, K.N);
         WorkDesc Wk{};

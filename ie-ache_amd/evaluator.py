@@ -122,6 +122,7 @@ def lib():
     L.ieache_ctx_force_generic.argtypes = [vp, C.c_int]
     L.ieache_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.ieache_ctx_fft_guard.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.ieache_ctx_fft_audit.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ieache_ctx_kernel_variant.restype = C.c_char_p
     L.ieache_ctx_kernel_variant.argtypes = [vp]
     L.ieache_circuit_info_get.argtypes = [C.c_int, C.c_int, C.POINTER(CircuitInfo)]
@@ -262,6 +263,13 @@ class Context:
         m, r = C.c_double(0), C.c_int64(0)
         check(lib().ieache_ctx_fft_guard(self.h, C.byref(m), C.byref(r)))
         return m.value, r.value
+
+    def fft_audit(self):
+        """The sampled bit-for-bit audit of the one-limb kernel against the two-limb one (option "fft_audit" = K):
+        {"audits": launches audited, "gates_compared": gate instances re-run and compared, "mismatches": rows that differed}."""
+        a, g, m = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().ieache_ctx_fft_audit(self.h, C.byref(a), C.byref(g), C.byref(m)))
+        return {"audits": a.value, "gates_compared": g.value, "mismatches": m.value}
 
     def set_chunk(self, items):
         check(lib().ieache_ctx_set_chunk(self.h, items))

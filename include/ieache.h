@@ -158,13 +158,20 @@ int ieache_ctx_wait_stream(ieache_ctx* ctx, void* hip_stream);
  * repeat itself on the two-limb kernel, counted in reruns).  Option "exact_fft" = 1 (or IEACHE_EXACT_FFT=1) uses the
  * two-limb kernel always.  Either pointer may be NULL. */
 int ieache_ctx_fft_guard(const ieache_ctx* ctx, double* max_deviation, int64_t* reruns);
+/* The guard watches the error LEVEL of every launch; the audit compares BITS of a sample: every K-th launch that took the
+ * one-FFT kernel (option "fft_audit" = K, default 64, 0 = off; IEACHE_FFT_AUDIT=K) has 64 of its gate instances run again on
+ * the two-limb kernel, and the extracted samples are compared word for word on the device.  A differing row makes the call
+ * repeat itself on the two-limb kernels (counted in `reruns` above).  audits: audits run by this context; gates_compared:
+ * gate instances they covered; mismatches: rows that differed (0 in every run so far).  Any pointer may be NULL.
+ * A call whose output buffer overlaps an input cannot be repeated, so it runs on the two-limb kernels from the start. */
+int ieache_ctx_fft_audit(const ieache_ctx* ctx, int64_t* audits, int64_t* gates_compared, int64_t* mismatches);
 /* same contract as ieache_cloud_run but with this context's resident key */
 int ieache_ctx_cloud_run(ieache_ctx* ctx, const char* workdir);
 /* tuning / test knobs */
 int ieache_ctx_set_chunk(ieache_ctx* ctx, int64_t gate_instances_per_launch);
 int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
 /* named knobs: "chunk", "force_generic", "ks_sliced_min", "ks_gates", "ks_slice", "ks_batch_min",
- * "br_slice", "br_wide_max", "br_variant", "exact_fft", "one_limb_min", "two_wave_max", "ks_split_max"
+ * "br_slice", "br_wide_max", "br_variant", "exact_fft", "fft_audit", "one_limb_min", "two_wave_max", "ks_split_max"
  * (see csrc/evaluator.h), and
  * "level_quantum" (0/1, default 1: the slack-balanced circuits -- 64/128-bit multipliers -- get a level
  * width that makes level x batch a whole number of resident-workgroup rounds; same DAG and output bits, more

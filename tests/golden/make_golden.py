@@ -239,6 +239,66 @@ def misc_n630():
     print("misc_n630.json written in %.0f s" % (time.time() - t0))
 
 
+CLOUD_N630_CASES = (
+    # name, operator.txt code, bit size, (sign code, value, alice seed) x 2
+    ("add16_in_32bit_word", 1, 32, (0, 0xBEEF, 4101), (0, 0x1234, 4102)),   # BASELINE configs[0]: 16-bit a+b, zero-extended in the 32-bit word
+    ("sub32", 2, 32, (0, 0x1234ABCD, 4103), (0, 0x0FEDCBA9, 4104)),
+    ("mul32", 4, 32, (0, 0xC0FFEE11, 4105), (0, 0x89ABCDEF, 4106)),
+)
+CLOUD_N630_KEY_SEED, CLOUD_N630_NBIT_SEED = (314, 1592, 657), (2718, 2818)
+
+
+def cloud_n630(only=None):
+    """The ./cloud FILE contract at the product parameter set (cloud.c:650-917): keygen from the documented seeds,
+    `alice` twice per case, then the oracle's orc_cloud_values on that cloud.data.  Committed per case: sha256 of
+    cloud.data's 704 samples, sha256 of the 288 value samples of answer.data (words r1..r8 + carry filler; the two
+    metadata words are fresh encryptions and compared by decryption), first and last value sample.
+    ~15 min on 8 cores (the 32-bit MUL is 11 264 exact bootstraps)."""
+    import tempfile
+    import time
+    p = ia.default_params()
+    S = p.n + 1
+    path = os.path.join(HERE, "cloud_n630.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    out.update({"params": "n=630 N=1024 k=1 l=3 Bgbit=7 ks_t=8 ks_basebit=2", "key_seed": list(CLOUD_N630_KEY_SEED),
+                "nbit_seed": list(CLOUD_N630_NBIT_SEED), "sample_bytes": 4 * p.n + 16,
+                "made_by": "tests/golden/make_golden.py cloud_n630 (keygen_files + alice x2 per case; oracle exact NTT back-end, "
+                           "orc_cloud_values in deferred level-parallel mode)"})
+    out.setdefault("cases", {})
+    with tempfile.TemporaryDirectory() as d:
+        tools.keygen_files(d, p, seed=CLOUD_N630_KEY_SEED, nbit_seed=CLOUD_N630_NBIT_SEED)
+        _, bk, ksk = tools.read_cloud_key(os.path.join(d, "cloud.key"))
+        _, lwe_key, _ = tools.read_secret_key(os.path.join(d, "secret.key"))
+        out["cloud_key_sha256"] = digest(bk, ksk)
+        ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, bk, ksk)
+        for name, op, bits, (sa, a, seed_a), (sb, b, seed_b) in CLOUD_N630_CASES:
+            if only and name not in only:
+                continue
+            t0 = time.time()
+            tools.alice(d, sa, bits, a, seed=seed_a)
+            tools.alice(d, sb, bits, b, seed=seed_b, append=True)
+            data = tools.read_samples(os.path.join(d, "cloud.data"), p.n)
+            assert data.shape == (704, S)
+            w = data.reshape(22, 32, S)
+            neg = {0: 0, 1: 1, 2: 1}[sa] + sb  # cloud.c:787-789: code 2 of operand 1 is remapped to 1
+            rc, ref = ck.cloud_values(op, neg, bits, np.ascontiguousarray(w[2:10]), np.ascontiguousarray(w[13:21]),
+                                      np.ascontiguousarray(w[10]), threads=0)
+            assert rc == 0
+            ref = np.ascontiguousarray(ref.reshape(288, S))
+            nw = (2 * bits if op == 4 else bits) // 32
+            val = tools.bits_to_int(tools.decrypt_bits(p, lwe_key, ref[:32 * nw]))
+            exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 4: a * b}[op]
+            assert val == exp, (name, hex(val), hex(exp))
+            out["cases"][name] = {"operator": op, "bits": bits, "a": a, "sign_a": sa, "seed_a": seed_a, "b": b, "sign_b": sb,
+                                  "seed_b": seed_b, "cloud_data_sha256": digest(data), "value_samples_sha256": digest(ref),
+                                  "first_value_sample": ref[0].tolist(), "last_value_sample": ref[-1].tolist(),
+                                  "expect": exp, "bootstraps": int(ck.bootstrap_count), "oracle_seconds": round(time.time() - t0, 1)}
+            print("cloud_n630 %s done in %.0f s" % (name, time.time() - t0), flush=True)
+            with open(path, "w") as f:
+                json.dump(out, f, indent=0)
+    print("cloud_n630.json written")
+
+
 def plaintext_kats():
     kats = []
     for bits in (32, 64, 128, 256):
@@ -267,6 +327,8 @@ if __name__ == "__main__":
         mul128_n630()
     elif sys.argv[1:] == ["misc_n630"]:      # ~6 min
         misc_n630()
+    elif sys.argv[1:2] == ["cloud_n630"]:    # ~15 min on 8 cores; optional case names after it
+        cloud_n630(sys.argv[2:] or None)
     else:
         toy_vectors()
         full_size_kat()

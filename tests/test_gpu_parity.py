@@ -366,6 +366,26 @@ def test_mul32_at_product_parameters_matches_golden(ia, gpu_ctx):
     batch = np.repeat(inp[None], 24, axis=0)
     outs = ctx.eval_batch(4, 32, batch)
     assert all(np.array_equal(outs[e], out) for e in range(24))
+    # the guard's repeat path on the golden: an (injected) guard trip re-runs the whole call on the two-limb kernels ...
+    r0 = ctx.fft_guard()[1]
+    ctx.set_option("fft_guard_inject", 1)
+    out2 = ctx.eval_batch(4, 32, inp[None])[0]
+    assert ctx.fft_guard()[1] == r0 + 1
+    assert hashlib.sha256(np.ascontiguousarray(out2).tobytes()).hexdigest() == g["output_sha256"]
+    # ... and so does a row the sampled audit finds different (every launch audited here)
+    ctx.set_option("fft_audit", 1)
+    ctx.set_option("fft_audit_inject", 1)
+    a0 = ctx.fft_audit()
+    out3 = ctx.eval_batch(4, 32, inp[None])[0]
+    a1 = ctx.fft_audit()
+    ctx.set_option("fft_audit", 64)
+    assert ctx.fft_guard()[1] == r0 + 2 and a1["mismatches"] == a0["mismatches"] + 1 and a1["audits"] > a0["audits"]
+    assert hashlib.sha256(np.ascontiguousarray(out3).tobytes()).hexdigest() == g["output_sha256"]
+    # the provably exact two-limb transform from the start: same bits
+    ctx.set_option("exact_fft", 1)
+    out4 = ctx.eval_batch(4, 32, inp[None])[0]
+    ctx.set_option("exact_fft", 0)
+    assert hashlib.sha256(np.ascontiguousarray(out4).tobytes()).hexdigest() == g["output_sha256"] and ctx.fft_guard()[1] == r0 + 2
 
 
 def test_muladd64_at_product_parameters_matches_golden(ia, gpu_ctx):
@@ -605,6 +625,56 @@ def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
     assert (tmp_path / "averagestandard.txt").exists()  # MUL timing log (cloud.c:2467-2471)
 
 
+def test_cloud_file_contract_at_product_parameters(ia, tmp_path):
+    """The ./cloud process contract at n=630 (cloud.c:650-917), through the `cloud` EXECUTABLE: keygen from the documented
+    seeds, `alice` twice, operator.txt, ./cloud in that directory, `verif` -- BASELINE configs[0] (16-bit a+b, zero-extended in
+    the 32-bit word), a 32-bit SUB and a 32-bit MUL.  2536-byte samples, the 114 MB key file through the codec, the fast
+    kernels behind ieache_cloud_run; the 288 value samples of answer.data equal what the oracle's orc_cloud_values made of
+    the same cloud.data (tests/golden/cloud_n630.json, make_golden.py cloud_n630).  A 256-bit MUL exits 126 and leaves
+    exactly the 162 304 bytes the reference's caller tests for (Cloud/dragonfly_cipher_cloud.py:1295, cloud.c:860-864)."""
+    import hashlib
+    from ieache_amd import tools
+    g = json.load(open(os.path.join(G, "cloud_n630.json")))
+    p = ia.default_params()
+    S = p.n + 1
+
+    def digest(*arrays):
+        h = hashlib.sha256()
+        for a in arrays:
+            h.update(np.ascontiguousarray(a).tobytes())
+        return h.hexdigest()
+
+    tools.keygen_files(tmp_path, p, seed=tuple(g["key_seed"]), nbit_seed=tuple(g["nbit_seed"]))
+    assert os.path.getsize(tmp_path / "cloud.key") > 113_000_000
+    _, bk, ksk = tools.read_cloud_key(tmp_path / "cloud.key")
+    assert digest(bk, ksk) == g["cloud_key_sha256"]
+    del bk, ksk
+    assert g["sample_bytes"] == 2536 == 4 * p.n + 16
+    for name, c in g["cases"].items():
+        tools.alice(tmp_path, c["sign_a"], c["bits"], c["a"], seed=c["seed_a"])
+        tools.alice(tmp_path, c["sign_b"], c["bits"], c["b"], seed=c["seed_b"], append=True)
+        assert os.path.getsize(tmp_path / "cloud.data") == 704 * 2536
+        assert digest(tools.read_samples(tmp_path / "cloud.data", p.n)) == c["cloud_data_sha256"], name
+        if (tmp_path / "answer.data").exists():
+            os.remove(tmp_path / "answer.data")
+        rc, size, ok = ia.compute({1: 1, 2: 2, 4: 3}[c["operator"]], tmp_path, use_subprocess=True)
+        assert (rc, ok) == (0, True) and size == 892672 == 352 * 2536, name
+        ans = tools.read_samples(tmp_path / "answer.data", p.n)
+        val = ans[64:]  # [neg, bit] are fresh encryptions (cloud.c:822-826); r1..r8 + the carry-word filler follow
+        assert val.shape == (288, S)
+        assert val[0].tolist() == c["first_value_sample"] and val[-1].tolist() == c["last_value_sample"], name
+        assert digest(val) == c["value_samples_sha256"], name
+        code, bit_size, words = tools.verif(tmp_path)
+        assert bit_size == (2 * c["bits"] if c["operator"] == 4 else c["bits"])
+        assert tools.verif_interpret(c["operator"], code, bit_size, words) == c["expect"], name
+    # 256-bit operands cannot be multiplied: exit code 126 and the 64 metadata samples only
+    tools.alice(tmp_path, 0, 256, 5, seed=1)
+    tools.alice(tmp_path, 0, 256, 7, seed=2, append=True)
+    os.remove(tmp_path / "answer.data")
+    rc, size, ok = ia.compute(3, tmp_path, use_subprocess=True)
+    assert rc == 126 and size == 162304 and not ok
+
+
 def _inplace_gates(ia, ctx, a, b):
     """gates_device with the output written over the first operand."""
     import torch
@@ -644,13 +714,16 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     ctx.set_option("br_slice", 16)
     # one wave per gate on the one-limb spectrum (the default for wide launches, which `ref` above took): with and without
     # the guard arithmetic, forward transposes through LDS / cross-lane, early BK requests; ragged last workgroup of 4 gates
-    for variant in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30):  # 20 / 21: two waves per gate on the one-limb spectrum; 22 / 23: 2L waves, a row each; 24-28: the latency kernel on one limb (transposes through LDS / cross-lane)
+    # 20 / 21: two waves per gate on the one-limb spectrum; 22 / 23: 2L waves, a row each; 24-28: the latency kernel on one limb
+    # (transposes through LDS / cross-lane); 31-35: round 3's k_blind_rotate_w1b (31 = the default of wide launches)
+    for variant in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35):
         ctx.set_option("br_variant", variant)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), variant
-    ctx.set_option("br_variant", 13)
-    for sl in (1, 5, 64):
-        ctx.set_option("br_slice", sl)
-        assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), sl
+    for variant in (13, 31):
+        ctx.set_option("br_variant", variant)
+        for sl in (1, 5, 64):
+            ctx.set_option("br_slice", sl)
+            assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), (variant, sl)
     ctx.set_option("br_slice", 16)
     ctx.set_option("br_variant", 0)
     dev, reruns = ctx.fft_guard()
@@ -662,9 +735,27 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
     assert ctx.fft_guard()[1] == 1
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref) and ctx.fft_guard()[1] == 1
+    # in-place call: it could not be repeated (the first attempt overwrites its inputs), so it runs on the two-limb kernels
+    # from the start -- right bits, no rerun counted, and an injected guard trip is simply folded away
     ctx.set_option("fft_guard_inject", 1)
-    with pytest.raises(ia.IeacheError, match="overlaps"):  # in-place call: the inputs are gone, so it cannot be repeated
-        _inplace_gates(ia, ctx, a[:600], b[:600])
+    assert np.array_equal(_inplace_gates(ia, ctx, a[:600], b[:600]), ref[:600]) and ctx.fft_guard()[1] == 1
+    # the sampled audit: with fft_audit = 1 every one-limb launch has 64 of its gates re-run on the two-limb kernel and compared
+    base = ctx.fft_audit()
+    ctx.set_option("fft_audit", 1)
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)           # one launch of 2304 gates: one audit of 64
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a[:37], b[:37]), ref[:37])  # latency kernel on one limb: all 37 audited
+    au = ctx.fft_audit()
+    assert au["audits"] == base["audits"] + 2 and au["gates_compared"] == base["gates_compared"] + 64 + 37
+    assert au["mismatches"] == base["mismatches"] == 0 and ctx.fft_guard()[1] == 1
+    ctx.set_option("fft_audit_inject", 1)                  # a differing row makes the call repeat itself on the two-limb kernels
+    assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
+    au2 = ctx.fft_audit()
+    assert au2["mismatches"] == 1 and au2["audits"] == au["audits"] + 1 and ctx.fft_guard()[1] == 2
+    ctx.set_option("exact_fft", 1)                         # nothing to audit on the two-limb kernels
+    ctx.gates(ia.GATE_AND, a[:600], b[:600])
+    assert ctx.fft_audit() == au2
+    ctx.set_option("exact_fft", 0)
+    ctx.set_option("fft_audit", 64)
     ctx.set_option("one_limb_min", 0)                      # one-limb kernel down to a single gate
     ctx.set_option("br_wide_max", 0)
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:1], b[:1]), ref[:1])
@@ -706,7 +797,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
     ctx.force_generic(False)
     with pytest.raises(ia.IeacheError):
-        ctx.set_option("br_variant", 31)
+        ctx.set_option("br_variant", 61)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("br_slice", 4097)
     with pytest.raises(ia.IeacheError):
@@ -1117,29 +1208,32 @@ def _run_file_contract_daemon(ia, tmp_path, sock, operator, bits, a, sa, b, sb):
 
 
 def test_bench_two_rank_flow_on_one_gpu(tmp_path):
-    """The N>1 path of bench.py end to end (key broadcast, batch sharding, max-over-ranks timing, one JSON
-    line from rank 0), rehearsed with CPU collectives so that both ranks can share this box's one GPU."""
-    import socket
+    """The N>1 path of bench.py end to end, started the way the driver starts it -- `python bench.py --gpus 2` with NO
+    torch.distributed.run environment, so bench.py launches its own ranks -- (key broadcast, batch sharding,
+    max-over-ranks timing, one JSON line from rank 0), rehearsed with CPU collectives so that both ranks can share this
+    box's one GPU."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--batch", "48", "--backend", "gloo", "--no-cpu-baseline", "--mul32-leg", "on", "--mul32-batch", "6"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--batch", "48", "--backend", "gloo", "--no-cpu-baseline", "--legs", "mul32,muladd64", "--mul32-batch", "6",
+           "--muladd64-batch", "2", "--extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path,
-                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                       env=dict(env, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["batch_per_gpu"] == 48 and out["config"]["parallelism"] == "batch-sharded x2"
-    assert "cpu_baseline" not in out and out["roofline"]["frac"] > 0 and out["roofline"]["bound"] == "fp64_valu"
+    rf = out["roofline"]
+    assert "cpu_baseline" not in out and rf["bound"] == "fp64_valu" and 0 < rf["frac"] == rf["frac_algorithmic_flops"] < 1
+    assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-9 and rf["algorithmic_flops_per_gate"] == 630 * 233472
     assert out["config"]["collective_backend"] == "gloo" and len(out["config"]["per_rank_gate_ops_per_s"]) == 2
-    # the second leg ran on both ranks too (its passes contain barriers: a rank skipping one would hang the other)
+    # the other legs ran on both ranks too (their passes contain barriers: a rank skipping one would hang the other)
     m = out["mul32"]
     assert m["batch_per_gpu"] == 6 and len(m["per_rank_gate_ops_per_s"]) == 2 and m["mul32_per_s"] == out["mul32_per_s"] > 0
     assert m["folded"]["executed_bootstraps_per_expr"] == 7568 and m["carry_save"]["levels"] == 37
+    ma = out["muladd64"]
+    assert ma["batch_per_gpu"] == 2 and ma["bootstraps_per_expr"] == 35936 and ma["roofline"]["frac"] > 0 and "mul128" not in out

@@ -182,6 +182,24 @@ def test_key_reader_tolerates_other_layouts(ia, tmp_path):
         got = k2.reshape(-1, 4, S)
         assert np.array_equal(got[:, 1:], ksk4[:, 1:]) and not got[:, 0].any(), name
         assert want in L.ieache_last_key_layout(), (name, L.ieache_last_key_layout())
+    # layouts of EQUAL size that differ only in where a variance double stands (no tags to tell them apart): the first
+    # eight bytes of a key-switch key that carries its d = 0 rows are zero and read as a perfectly plausible variance
+    # 0.0, so [KSK][var][BK] also "fits" [var][KSK][BK] -- shifted by eight bytes.  The all-zero d = 0 rows decide.
+    for name, blob in (("var_after_ksk", G + LW + TL + TG + ksk.tobytes() + f64(2.0 ** -30) + bk.tobytes()),
+                       ("var_before_ksk", G + LW + TL + TG + f64(0.0) + ksk.tobytes() + bk.tobytes())):
+        f = tmp_path / (name + ".key")
+        f.write_bytes(blob)
+        q, b2, k2 = tools.read_cloud_key(f)
+        assert np.array_equal(b2, bk) and np.array_equal(k2, ksk), (name, L.ieache_last_key_layout())
+    # ... and where the structure cannot decide (here: d = 0 rows omitted, so nothing is known to be zero, and the eight
+    # bytes in question are plausible either way) the reader refuses instead of guessing
+    amb = G + LW + TL + TG + f64(0.0) + np.ascontiguousarray(ksk4[:, 1:]).tobytes() + bk.tobytes()
+    (tmp_path / "amb.key").write_bytes(amb)
+    try:
+        q, b2, k2 = tools.read_cloud_key(tmp_path / "amb.key")
+        assert np.array_equal(b2, bk) and np.array_equal(k2.reshape(-1, 4, S)[:, 1:], ksk4[:, 1:])  # decoded right ...
+    except ia.IeacheError as e:
+        assert "ambiguous key layout" in str(e)                                                    # ... or refused, never shifted
     # secret key sets: keys before the cloud body, untagged, TGSW key first
     sraw = (tmp_path / "secret.key").read_bytes()
     _, sbody = _sections(sraw)
