@@ -35,7 +35,7 @@ int gates_per_workgroup_w1();
 size_t twiddle_table_elems();
 void build_twiddle_table(double2* d_tw, hipStream_t stream);
 // Kernel variants ("br_variant" / IEACHE_BR_VARIANT; all produce identical bits).  0 lets the EVALUATOR choose by launch
-// size (evaluator.hip: <= one gate per CU -> 24, <= 4 per CU -> 20, above -> 13; "exact_fft": 7 / 0); passed to launch()
+// size (evaluator.hip: <= one gate per CU -> 38, <= 4 per CU -> 36, above -> 31; "exact_fft": 7 / 0); passed to launch()
 // itself, 0 is the two-limb two-wave kernel.
 //   two limbs (exact by construction), two waves per gate -- k_blind_rotate_w2:
 //     0  wave-local sync, the forward transforms' lane-high transpose cross-lane (v_permlane*_swap / DPP), every other
@@ -54,13 +54,20 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //     22 / 23 every wave a whole row, no hand-over -- k_blind_rotate_wide1 (measured slower; 23 without guard arithmetic)
 //     24 k_blind_rotate_wide on the one-limb spectrum (narrow launches)   25-28 its transposes cross-lane (slower)
 //     29 24 with phase stamps
+//   round 3 (all on the one-limb spectrum; guard on one rounded coefficient in four unless noted):
+//     31 k_blind_rotate_w1b: k_blind_rotate_w1 with the index / sign arithmetic of the decomposition rewritten -- the
+//        default of wide launches   32 guard on every coefficient   33 / 34 some forward transposes through LDS   35 no guard
+//     36 k_blind_rotate_w2r: two waves per gate, the ROWS of BK_i split between them, one hand-over per step -- the default
+//        of mid-size launches   37 guard on every coefficient
+//     38 k_blind_rotate_wide4: 2L waves per gate, four output waves on half the rows each, no barrier B -- the default of
+//        narrow launches   39 guard on every coefficient
 int32_t default_variant();
 constexpr int32_t kVariantWide = 7;
 constexpr int32_t kVariantOneLimb = 13;
 constexpr int32_t kVariantOneLimbDefault = 31;  // k_blind_rotate_w1b, guard on one coefficient in four (round 3)
-constexpr int32_t kVariantOneLimbTwoWaves = 20;
+constexpr int32_t kVariantOneLimbTwoWaves = 36;     // k_blind_rotate_w2r (round 3; round 2's k_blind_rotate_w2s = 20)
 constexpr int32_t kVariantWideOneLimb = 22;
-constexpr int32_t kVariantWideHandoverOneLimb = 24;
+constexpr int32_t kVariantWideHandoverOneLimb = 38;  // k_blind_rotate_wide4 (round 3; round 2's k_blind_rotate_wide on one limb = 24)
 
 }  // namespace w64
 }  // namespace ieache

@@ -297,7 +297,25 @@ int ieache_circuit_info_get_ex(int kind, int bits, int fold_constants, ieache_ci
         return 0;
     });
 }
-int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out) { return ieache_circuit_info_get_ex(kind, bits, 0, out); }
+// The 0.1 entry point: its callers were compiled against the 56-byte struct (through `folded`), so it writes exactly that
+// prefix.  The fields added since are reached through the _ex / _cap entry points, which take the current struct.
+int ieache_circuit_info_get(int kind, int bits, ieache_circuit_info* out) {
+    if (!out) return fail(IEACHE_EINVAL, "null argument");
+    ieache_circuit_info full;
+    memset(&full, 0, sizeof full);  // padding included: the prefix is copied bytewise
+    const int rc = ieache_circuit_info_get_ex(kind, bits, 0, &full);
+    if (rc == 0) memcpy(out, &full, IEACHE_CIRCUIT_INFO_V01_BYTES);
+    return rc;
+}
+
+int ieache_ctx_circuit_level_cap(const ieache_ctx* ctx, int kind, int bits, int64_t batch) {
+    return guarded([&] {
+        if (!ctx) return fail(IEACHE_EINVAL, "null context");
+        Circuit c;
+        if (!build_circuit(kind, bits, &c, true, ctx->fold)) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
+        return (int)circuit_level_cap(c, batch, ctx->eval->resident_gates(), ctx->eval->resident_gates_two_wave());
+    });
+}
 
 int ieache_circuit_level_cap(int kind, int bits, int fold_constants, int64_t batch, int resident_workgroups) {
     return guarded([&] {

@@ -8,6 +8,11 @@
 // one libtfhe bootstrap at a time.
 #include "cloud_run.h"
 
+#include <map>
+#include <memory>
+#include <mutex>
+#include <tuple>
+
 #include <sys/time.h>
 
 #include <cstdio>
@@ -273,11 +278,28 @@ int cloud_run_io(const CloudRunIO& io, const std::function<Evaluator*()>& get_ev
 void cloud_eval_jobs(Evaluator& eval, const std::vector<CloudJob*>& jobs, std::vector<std::vector<Torus32>>* outs, EvalStats* stats) {
     if (jobs.empty()) return;
     const CloudJob& first = *jobs[0];
-    Circuit base, capped;
-    if (!build_circuit(first.kind, first.int_bit, &base, true, first.fold)) throw std::invalid_argument("unsupported circuit");
-    const Circuit* circ = &base;
-    const int32_t cap = circuit_level_cap(base, (int64_t)jobs.size(), eval.resident_gates(), eval.resident_gates_two_wave());
-    if (cap > 0 && build_circuit(first.kind, first.int_bit, &capped, true, first.fold, cap) && capped.balanced_schedule) circ = &capped;
+    // built circuits are kept for the life of the process (a daemon evaluates the same handful over and over; building the
+    // 128-bit multiplier's DAG and levelising it takes longer than evaluating a small batch of it), keyed like capi.cpp's
+    // per-context cache: (kind, width, folding, level cap)
+    static std::mutex cache_mutex;
+    static std::map<std::tuple<int32_t, int32_t, bool, int32_t>, std::unique_ptr<Circuit>> cache;
+    auto fetch = [&](int32_t cap) -> const Circuit* {
+        std::lock_guard<std::mutex> lock(cache_mutex);
+        const auto key = std::make_tuple(first.kind, first.int_bit, first.fold, cap);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second.get();
+        std::unique_ptr<Circuit> c(new Circuit);
+        if (!build_circuit(first.kind, first.int_bit, c.get(), true, first.fold, cap)) return nullptr;
+        return cache.emplace(key, std::move(c)).first->second.get();
+    };
+    const Circuit* base = fetch(0);
+    if (!base) throw std::invalid_argument("unsupported circuit");
+    const Circuit* circ = base;
+    const int32_t cap = circuit_level_cap(*base, (int64_t)jobs.size(), eval.resident_gates(), eval.resident_gates_two_wave());
+    if (cap > 0) {
+        const Circuit* capped = fetch(cap);
+        if (capped && capped->balanced_schedule) circ = capped;
+    }
     const size_t S = (size_t)first.params.n + 1, n_in = (size_t)circ->n_inputs * S, n_out = circ->outputs.size() * S;
     std::vector<Torus32> in(jobs.size() * n_in), out(jobs.size() * n_out);
     for (size_t i = 0; i < jobs.size(); i++) {

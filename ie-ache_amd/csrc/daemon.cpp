@@ -416,8 +416,15 @@ int64_t daemon_serve(const DaemonConfig& cfg) {
     while (running && !g_stop && (cfg.max_requests < 0 || served < cfg.max_requests)) {
         std::vector<std::unique_ptr<Fd>> conns;
         std::vector<Server::Pending> reqs;
-        auto take = [&](int fd) {  // reads one request; returns false when the client went away or sent garbage that was answered
+        // A request is a header and a payload written back to back by the client library; a peer that connects and then
+        // stalls must not hold up the requests already gathered in this round, so every connection reads under a receive
+        // deadline (generous for the connection that opens a round -- nobody is waiting yet --, the batching window for
+        // the ones that join it) and is dropped when it misses it.  The payloads buffered in one round are capped too.
+        size_t round_bytes = 0;
+        auto take = [&](int fd, int deadline_ms) {  // reads one request; a client that went away, stalled or sent garbage is answered or dropped here
             std::unique_ptr<Fd> c(new Fd(fd));
+            struct timeval tv{deadline_ms / 1000, (deadline_ms % 1000) * 1000};
+            (void)setsockopt(c->fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
             ReqHeader h{};
             if (!read_full(c->fd, &h, sizeof h)) return;
             Server::Pending p;
@@ -430,14 +437,21 @@ int64_t daemon_serve(const DaemonConfig& cfg) {
                 p.op = 0;
                 p.rc = IEACHE_EINVAL;
                 p.log = "payload too large";
+            } else if (round_bytes + h.payload_len > kDaemonMaxRoundBytes) {
+                p.op = 0;
+                p.rc = IEACHE_EINVAL;
+                p.log = "cloudd: this round's request buffer is full; send the request again";
             } else {
                 try {
                     p.payload.resize((size_t)h.payload_len);
                 } catch (const std::bad_alloc&) {
                     return;
                 }
-                if (h.payload_len && !read_full(c->fd, p.payload.data(), p.payload.size())) return;
+                if (h.payload_len && !read_full(c->fd, p.payload.data(), p.payload.size())) return;  // includes a missed deadline
+                round_bytes += p.payload.size();
             }
+            tv = {0, 0};  // the reply is written without a deadline
+            (void)setsockopt(c->fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
             conns.push_back(std::move(c));
             reqs.push_back(std::move(p));
         };
@@ -446,7 +460,7 @@ int64_t daemon_serve(const DaemonConfig& cfg) {
             if (errno == EINTR && !g_stop) continue;
             break;
         }
-        take(first);
+        take(first, kDaemonFirstRecvMs);
         if (window_ms > 0) {
             struct timeval t0;
             gettimeofday(&t0, nullptr);
@@ -460,7 +474,7 @@ int64_t daemon_serve(const DaemonConfig& cfg) {
                 if (pr <= 0 || !(pfd.revents & POLLIN)) break;
                 const int fd = accept(lfd.fd, nullptr, nullptr);
                 if (fd < 0) break;
-                take(fd);
+                take(fd, std::max(kDaemonJoinRecvMinMs, window_ms));
             }
         }
         // requests refused while reading (op 0) keep their canned answer; the rest goes through the server

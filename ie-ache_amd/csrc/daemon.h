@@ -30,6 +30,9 @@ constexpr uint32_t kDaemonMagic = 0x43414549u;  // "IEAC"
 constexpr uint32_t kDaemonVersion = 1;
 enum DaemonOp : uint32_t { DAEMON_PING = 1, DAEMON_RUN_DIR = 2, DAEMON_RUN_DATA = 3, DAEMON_SHUTDOWN = 4, DAEMON_STATS = 5 };
 constexpr uint64_t kDaemonMaxPayload = 64ull << 20;  // cloud.data is 1.8 MB at n=630
+constexpr uint64_t kDaemonMaxRoundBytes = 1ull << 30;  // request payloads buffered in one batching round (256 x 1.8 MB = 0.45 GB)
+// receive deadlines: the connection that opens a round / one that joins a batching round (at least this, else the window)
+constexpr int kDaemonFirstRecvMs = 5000, kDaemonJoinRecvMinMs = 250;
 
 struct DaemonConfig {
     std::string socket_path;

@@ -128,6 +128,7 @@ def lib():
     L.ieache_circuit_info_get.argtypes = [C.c_int, C.c_int, C.POINTER(CircuitInfo)]
     L.ieache_circuit_info_get_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(CircuitInfo)]
     L.ieache_circuit_level_cap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]
+    L.ieache_ctx_circuit_level_cap.argtypes = [vp, C.c_int, C.c_int, C.c_int64]
     L.ieache_circuit_info_get_cap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(CircuitInfo)]
     L.ieache_circuit_simulate_cap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p]
     L.ieache_circuit_simulate.argtypes = [C.c_int, C.c_int, u8p, u8p]
@@ -191,7 +192,8 @@ def circuit_info(kind, bits, fold=False, level_cap=0):
 
 
 def circuit_level_cap(kind, bits, batch, resident_workgroups=1024, fold=False):
-    """Level width a context picks for `batch` expressions ("level_quantum"); 0 = the default schedule."""
+    """Level width for `batch` expressions on a GPU that holds `resident_workgroups` blind rotations at once ("level_quantum");
+    0 = the default schedule.  What a given context picks (its device's residency, both kernels): Context.circuit_level_cap."""
     return check(lib().ieache_circuit_level_cap(kind, bits, int(fold), int(batch), int(resident_workgroups)))
 
 
@@ -263,6 +265,10 @@ class Context:
         m, r = C.c_double(0), C.c_int64(0)
         check(lib().ieache_ctx_fft_guard(self.h, C.byref(m), C.byref(r)))
         return m.value, r.value
+
+    def circuit_level_cap(self, kind, bits, batch):
+        """Level width this context's eval_batch* uses for `batch` expressions; 0 = the default schedule."""
+        return check(lib().ieache_ctx_circuit_level_cap(self.h, kind, bits, int(batch)))
 
     def fft_audit(self):
         """The sampled bit-for-bit audit of the one-limb kernel against the two-limb one (option "fft_audit" = K):

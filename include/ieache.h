@@ -109,6 +109,10 @@ typedef struct ieache_circuit_info {
     int32_t sched_levels;    /* levels the executor runs (== depth unless a level cap stretched the schedule) */
     int32_t level_cap;       /* the cap this schedule was built with (0 = mean ASAP width) */
 } ieache_circuit_info;
+/* the struct of header version 0.1 ended with `folded`: ieache_circuit_info_get() -- the entry point that existed then --
+ * writes these bytes and no more, so a caller built against that header is not written past its struct; the later
+ * fields come from ieache_circuit_info_get_ex / _get_cap */
+#define IEACHE_CIRCUIT_INFO_V01_BYTES 56
 
 const char* ieache_version(void);
 const char* ieache_last_error(void);
@@ -196,6 +200,9 @@ int ieache_circuit_info_get_ex(int kind, int bits, int fold_constants, ieache_ci
 /* the schedule a context would pick for `batch` expressions on a GPU holding `resident_workgroups` blind rotations
  * at once (4 per CU; "level_quantum"): level_cap = 0 reproduces ieache_circuit_info_get_ex */
 int ieache_circuit_level_cap(int kind, int bits, int fold_constants, int64_t batch, int resident_workgroups);
+/* ... the same for the GPU and the kernels THIS context runs (one-wave and two-wave residency of its device, its
+ * fold_constants setting): the level width ieache_eval_batch* will use for `batch` expressions; 0 = the default schedule */
+int ieache_ctx_circuit_level_cap(const ieache_ctx* ctx, int kind, int bits, int64_t batch);
 int ieache_circuit_info_get_cap(int kind, int bits, int fold_constants, int level_cap, ieache_circuit_info* out);
 int ieache_circuit_simulate_cap(int kind, int bits, int fold_constants, int level_cap, const uint8_t* in_bits, uint8_t* out_bits);
 /* host buffers: in [batch][n_inputs][n+1], out [batch][n_outputs][n+1] */

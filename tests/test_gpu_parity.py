@@ -1189,6 +1189,23 @@ def test_daemon_batches_concurrent_requests(ia, O, tmp_path):
         bad.join(timeout=120)
         good.join(timeout=120)
         assert results[0][0] == -5 and results[1][0] == 0 and len(results[1][2]) == 352 * S
+        # a peer that connects during a round and then sends nothing misses the receive deadline (the batching window,
+        # 400 ms here) and is dropped: the request that opened the round is answered without waiting for it
+        import socket
+        import time
+        first = threading.Thread(target=lambda: results.__setitem__(2, daemon.run_data(sock, 1, (jobs[2][0] / "cloud.data").read_bytes())))
+        t0 = time.perf_counter()
+        first.start()
+        time.sleep(0.1)
+        staller = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        staller.connect(os.fspath(sock))
+        staller.sendall(b"\x01\x02\x03")  # a fragment of a header, then silence
+        first.join(timeout=120)
+        took = time.perf_counter() - t0
+        assert results[2][0] == 0 and len(results[2][2]) == 352 * S and took < 30, took
+        assert staller.recv(16) == b""       # the daemon closed the stalled connection
+        staller.close()
+        assert daemon.ping(sock)[0] == 0
         assert daemon.shutdown(sock) == 0
         assert proc.wait(timeout=60) == 0
     finally:

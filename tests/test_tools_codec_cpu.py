@@ -24,6 +24,21 @@ def test_c_abi_exports_every_declared_symbol(ia):
     assert b"gfx950" in L.ieache_version() if not isinstance(L.ieache_version(), int) else True
 
 
+def test_circuit_info_entry_point_of_header_0_1_writes_its_own_struct_only(ia):
+    """ieache_circuit_info grew from 56 to 72 bytes after header version 0.1; ieache_circuit_info_get() existed then, so it
+    fills the 56-byte prefix and leaves what follows in the caller's memory alone.  _get_ex fills the current struct."""
+    L = ia.lib()
+    buf = (ctypes.c_ubyte * 96)(*([0xAB] * 96))
+    L.ieache_circuit_info_get.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    assert L.ieache_circuit_info_get(ia.CIRC_MUL, 32, buf) == 0
+    L.ieache_circuit_info_get.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ia.CircuitInfo)]
+    raw = bytes(buf)
+    assert raw[56:] == b"\xab" * 40
+    full = ia.circuit_info(ia.CIRC_MUL, 32)
+    assert ctypes.sizeof(ia.CircuitInfo) == 72 and raw[:56] == bytes(full)[:56]
+    assert full.bootstraps == 11264 == full.reference_bootstraps and full.sched_levels == full.depth == 255
+
+
 def test_default_params_are_libtfhe_128bit(ia):
     p = ia.default_params()
     assert (p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit) == (630, 1024, 1, 3, 7, 8, 2)
