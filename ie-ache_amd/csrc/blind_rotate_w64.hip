@@ -1384,8 +1384,10 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const do
 // LIMBS = 1: the same kernel on the one-limb spectrum [n][2L][2][8][64] -- waves 0 and 1 own the two output polynomials,
 // half the BK bytes and LDS reads per step, guarded rounding (`guard`, see k_blind_rotate_w1).
 // XF / XI: which transposes of the forward / inverse transform go cross-lane instead of through LDS (bit 0 lane-high, bit 1 lane-low)
-template <int L, int BGBIT, bool DIAG, int LIMBS = 2, int XF = 0, int XI = 0>
-__global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const double2* __restrict__ bkf,
+// MINW: waves per SIMD the build must allow (3: at most 168 VGPRs, so that TWO workgroups of 2L = 6 waves share a CU --
+// launches of one to two gates per CU)
+template <int L, int BGBIT, bool DIAG, int LIMBS = 2, int XF = 0, int XI = 0, int MINW = 1>
+__global__ __launch_bounds__(128 * L, MINW) void k_blind_rotate_wide(DevKeys K, const double2* __restrict__ bkf,
                                                              const uint16_t* __restrict__ st_bara, int32_t nb,
                                                              int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
                                                              unsigned long long* diag, const double2* __restrict__ gtw,
@@ -1685,6 +1687,164 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
                 }
             }
             fft512_inverse<true, 0>(s, sTi, lane, R);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
+                const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
+                const double t0 = z.x + kMagic, t1 = z.y + kMagic;
+                if (watched) dev_max = fmax(dev_max, fmax(fabs(z.x - (t0 - kMagic)), fabs(z.y - (t1 - kMagic))));
+                const int32_t j = 64 * r + lane;
+                atomicAdd(&acco[j], (uint32_t)__double2loint(t0));  // ds_add_u32; the other half of this output adds to the same word
+                atomicAdd(&acco[j + kM], (uint32_t)__double2loint(t1));
+            }
+        }
+        __syncthreads();  // C: accumulator complete before the next decomposition; every published spectrum consumed
+    }
+    if (GUARD && is_out) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
+        }
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = tid; j <= kN; j += NT)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+        for (int idx = tid; idx < 2 * kN / 4; idx += NT) dst[idx] = src[idx];
+    }
+}
+
+// ---- K3 (+K4), one to two gates per CU, round 3: k_blind_rotate_wide4 built so that TWO workgroups share a CU ----
+// Launches of 257 .. 512 gate instances: one workgroup of 2L waves per gate as in k_blind_rotate_wide4, but at most 168 VGPRs
+// (three waves per SIMD) and 74 KB of LDS (the inverse transforms reuse the published tiles after a barrier B instead of
+// scratch tiles of their own), so that two gates are resident per CU and fill each other's waits.  An output wave's L BK
+// blocks are requested after its forward transform (they do not fit the register budget next to it) and arrive under
+// barrier A and the other workgroup's work, two in flight at a time.
+// k_blind_rotate_wide on the one-limb spectrum leaves the six row products and the inverse transform of an output
+// polynomial to ONE wave (two output waves; the other four idle for half of the step), and its tiles serve both as the
+// published spectra and as the inverse transforms' scratch (barrier B).  Here waves 0..3 are output waves (one per SIMD):
+// output wave (c, h) = (w & 1, w >> 1) multiplies the L published spectra of accumulator polynomial h with block c of
+// their BK rows -- its L blocks are requested at the top of the step and arrive under the decomposition and the forward
+// transform --, inverse-transforms that PARTIAL sum in a scratch tile of its own (no barrier B), rounds it and adds it
+// into accumulator polynomial c with ds_add_u32.  Each partial sum is an integer polynomial and addition mod 2^32
+// commutes, so the two halves of an output need no ordering.  Two barriers per step (spectra published / accumulator
+// updated).  Same rounded integers as every other kernel here.
+// dynamic LDS: acc [2][1024] int32 | sT [2L][kTile] double2 | tw [kTwElems] double2 | bara [i1-i0] u16
+template <int L, int BGBIT, int GUARD>
+__global__ __launch_bounds__(128 * L, 3) void k_blind_rotate_wide4b(DevKeys K, const double2* __restrict__ bkf1,
+                                                              const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                              int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
+                                                              unsigned* guard, const double2* __restrict__ gtw) {
+    constexpr int NW = 2 * L, NT = 64 * NW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    int32_t* acc = reinterpret_cast<int32_t*>(smem);
+    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)2 * kN * 4);
+    double2* sTw = sT_all + NW * kTile;
+    uint16_t* s_bara = reinterpret_cast<uint16_t*>(sTw + kTwElems);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;                  // forward scratch, then this wave's published spectrum
+    const int64_t item = (int64_t)blockIdx.x;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    load_twiddles(sTw, gtw, tid, NT);
+    const LaneRoots R = make_roots(sTw, lane);
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+        for (int idx = tid; idx < 2 * kN / 4; idx += NT) dst[idx] = src[idx];
+        const uint16_t* bara = st_bara + (size_t)item * nb;
+        for (int idx = tid; idx < i1 - i0; idx += NT) s_bara[idx] = bara[i0 + idx];
+    }
+    __syncthreads();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;
+    const int pw = wave / L, qw = wave - pw * L;  // forward role: digit qw of polynomial pw = row `wave` of BK_i
+    const int sh = 32 - (qw + 1) * BGBIT;
+    const bool is_out = wave < 4;
+    const int oc = wave & 1, oh = (wave >> 1) & 1;  // output role: block oc of the rows of polynomial oh
+    uint32_t* acco = reinterpret_cast<uint32_t*>(acc) + oc * kN;
+    const unsigned char* accb = reinterpret_cast<const unsigned char*>(acc);
+    const uint32_t pb = (uint32_t)pw * (kN * 4);
+    const int32_t* accp = acc + pw * kN;
+    double dev_max = 0.0;
+
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readfirstlane((int32_t)s_bara[i - i0]);
+        if (a == 0) continue;  // workgroup-uniform
+        // BK_i rows [2L][2][8][64]: this output wave's L blocks, all requested now
+        const double2* __restrict__ bki = bkf1 + (size_t)i * (2 * L * 2 * kM) + (size_t)(oh * L) * (2 * kM) + (size_t)oc * kM + lane;
+        int32_t lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // opaque: keeps the per-coefficient LDS addresses from being hoisted out of the step loop
+        const uint32_t jb4 = ((uint32_t)(lane_o - a) & (2 * kN - 1)) << 2;
+        uint32_t rv0[8], rv1[8], pv0[8], pv1[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {   // all 32 LDS reads first, then the arithmetic
+            const uint32_t t = jb4 + 256u * r;
+            const uint32_t o0 = (t & 4092u) | pb, o1 = o0 ^ 2048u;
+            rv0[r] = *reinterpret_cast<const uint32_t*>(accb + o0);
+            rv1[r] = *reinterpret_cast<const uint32_t*>(accb + o1);
+            pv0[r] = (uint32_t)accp[64 * r + lane_o];
+            pv1[r] = (uint32_t)accp[64 * r + lane_o + kM];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t t = jb4 + 256u * r;
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)t, 12, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int32_t)(t + 2048u), 12, 1);
+            const uint32_t u0 = (rv0[r] ^ m0) + ((dec_offset - pv0[r]) - m0);
+            const uint32_t u1 = (rv1[r] ^ m1) + ((dec_offset - pv1[r]) - m1);
+            // digit - halfBg = sign-extended field of (u ^ (halfBg << sh))
+            const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)(u0 ^ (halfBg << sh)), sh, BGBIT);
+            const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
+            x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                          : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+        }
+        fft512_forward<true, 0>(x, sT, lane, R);
+#pragma unroll
+        for (int k = 0; k < 8; k++) sT[k * 64 + lane] = x[k];  // publish
+        __builtin_amdgcn_sched_barrier(0);
+        double2 bka[8], bkb[8];  // two of this output wave's L BK blocks in flight at a time (all L do not fit 168 registers)
+        if (is_out) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) bka[k] = bki[k * 64];
+        }
+        __syncthreads();  // A: all 2L spectra are in their tiles
+        double2 s[8];
+        if (is_out) {
+#pragma unroll
+            for (int q = 0; q < L; q++) {
+                double2 (&cur)[8] = (q & 1) ? bkb : bka;
+                double2 (&nxt)[8] = (q & 1) ? bka : bkb;
+                if (q + 1 < L) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) nxt[k] = bki[(size_t)(q + 1) * (2 * kM) + k * 64];
+                }
+                const double2* sp = sT_all + (oh * L + q) * kTile + lane;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const double2 y = sp[k * 64];
+                    s[k] = q == 0 ? cmulx<false>(y, cur[k])
+                                  : make_double2(fma(y.x, cur[k].x, fma(-y.y, cur[k].y, s[k].x)), fma(y.x, cur[k].y, fma(y.y, cur[k].x, s[k].y)));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // B: every published spectrum consumed; the tiles are scratch again
+        if (is_out) {
+            fft512_inverse<true, 0>(s, sT, lane, R);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
@@ -2040,6 +2200,24 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
                            st_acc, items, i0, i1, e, guard, gtw);                                                               \
     }
+    if (sub == 28) {  // round 3: k_blind_rotate_wide4 built for two workgroups per CU (launches of one to two gates per CU)
+        const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
+        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_wide4b<L, BGBIT, 2>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide4b");
+        hipLaunchKernelGGL((k_blind_rotate_wide4b<L, BGBIT, 2>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, d_bkf1, st_bara, nb,
+                           st_acc, i0, i1, e, guard, gtw);
+        return;
+    }
+    if (sub == 27) {  // round 3 experiment: k_blind_rotate_wide on one limb built for two workgroups per CU (<= 168 VGPRs)
+        const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
+        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, false, 1, 0, 0, 3>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide<1 limb, 2 per CU>");
+        hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false, 1, 0, 0, 3>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, d_bkf1,
+                           st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr, gtw, guard);
+        return;
+    }
     if (sub == 25 || sub == 26) {  // round 3: latency kernel with four output waves on half the rows each; 26 = guard on every coefficient
         const size_t lds_w4 = (size_t)((2 * L + 4) * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
         static const bool attr_set =
@@ -2112,7 +2290,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
     const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || (variant >= kVariantWideOneLimb && variant <= kVariantWideOneLimb + 7) ||
-                               variant == kVariantOneLimb + 25 || variant == kVariantOneLimb + 26) ? nb : 64;
+                               variant == kVariantOneLimb + 25 || variant == kVariantOneLimb + 26 || variant == kVariantOneLimb + 27 || variant == kVariantOneLimb + 28) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "blind_rotate_w64.h"
+#include "keyswitch_mfma.h"
 #include "keyswitch_sliced.h"
 #include "device_common.h"
 
@@ -562,6 +563,14 @@ struct Evaluator::Impl {
     int64_t ks_sliced_min = 576;  // ... and used from this many gate instances per launch (measured crossover with the per-gate kernel: ~560)
     int32_t ks_slice = 0;         // coefficients per launch of the sliced key switch; 0 = the whole walk
     int32_t ks_gates = 0;         // gate instances per workgroup there (8 / 16 / 32); 0 = by launch size
+    // key switch as an int8 product on the MFMA pipe (keyswitch_mfma.hip): byte-limb form of the key, digit scratch, and the
+    // launch size from which it takes over from the hand-scheduled walk
+    int8_t* ks_limbs = nullptr;
+    void* ks_digits = nullptr;
+    size_t ks_digits_bytes = 0;
+    bool ks_mfma_ok = false;
+    int64_t ks_mfma_min = 64;     // measured crossover with the per-gate walk: ~40 gates (0.08 ms either way)
+    int32_t ks_mfma_split = 0;    // K split of the product; 0 = by launch size
     int32_t ks_split_max = 16;    // per-gate key switch: workgroups one gate's walk may be cut into when the launch is tiny
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
     int32_t br_variant = w64::default_variant();
@@ -652,6 +661,8 @@ void Evaluator::init() {
         if (const char* e = getenv("IEACHE_KS_BATCH_MIN")) d_->ks_batch_min = atoll(e);
         d_->ks_sliced_ok = kss::supported(p) && nld <= 4;
         if (const char* e = getenv("IEACHE_KS_SLICED_MIN")) d_->ks_sliced_min = atoll(e);
+        d_->ks_mfma_ok = ksm::supported(p);
+        if (const char* e = getenv("IEACHE_KS_MFMA_MIN")) d_->ks_mfma_min = atoll(e);
         if (d_->ks_batch_ok)
             HIP_CHECK(hipFuncSetAttribute((const void*)k_keyswitch_batch<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)((size_t)16 * p.N * 2 + 64)));
@@ -678,6 +689,8 @@ void Evaluator::destroy() {
     (void)hipFree(d_->audit_ext);
     (void)hipFree(d_->audit_state);
     (void)hipFree(d_->ksk);
+    (void)hipFree(d_->ks_limbs);
+    (void)hipFree(d_->ks_digits);
     (void)hipFree(d_->twist);
     (void)hipFree(d_->wtab);
     (void)hipFree(d_->ext);
@@ -720,6 +733,10 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->ks_slice = (int32_t)value;
     } else if (name == "ks_gates" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32)) {
         d_->ks_gates = (int32_t)value;
+    } else if (name == "ks_mfma_min" && value >= 0) {
+        d_->ks_mfma_min = value;
+    } else if (name == "ks_mfma_split" && value >= 0 && value <= 64) {
+        d_->ks_mfma_split = (int32_t)value;
     } else if (name == "ks_split_max" && value >= 1 && value <= 64) {
         d_->ks_split_max = (int32_t)value;
     } else if (name == "br_wide_max" && value >= 0) {
@@ -812,6 +829,11 @@ void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
     hipLaunchKernelGGL(k_pad_rows, dim3(2048), dim3(256), 0, stream_, d_ksk, d_->ksk, (int64_t)ks_rows, p_.n + 1,
                        K.stride);
     HIP_CHECK(hipGetLastError());
+    if (d_->ks_mfma_ok) {
+        if (!d_->ks_limbs) HIP_CHECK(hipMalloc(&d_->ks_limbs, ksm::limb_matrix_bytes(p_)));
+        ksm::prepare(p_, d_->ksk, d_->ks_limbs, stream_);
+        HIP_CHECK(hipGetLastError());
+    }
     HIP_CHECK(hipStreamSynchronize(stream_));
     keys_loaded_ = true;
 }
@@ -921,6 +943,19 @@ static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkD
     const DevKeys& K = d->K;
     const dim3 grid((unsigned)cnt), blk(kKsThreads);
     const int nld = force_generic ? 0 : d->ks_nld;
+    if (!force_generic && d->ks_mfma_ok && d->ks_limbs && cnt >= d->ks_mfma_min) {
+        const size_t need = ksm::digit_scratch_bytes(d->p, cnt);
+        if (d->ks_digits_bytes < need) {
+            if (d->ks_digits) HIP_CHECK(hipFree(d->ks_digits));
+            d->ks_digits = nullptr;
+            d->ks_digits_bytes = 0;
+            const size_t want = std::max(need, ksm::digit_scratch_bytes(d->p, (int64_t)d->chunk));
+            HIP_CHECK(hipMalloc(&d->ks_digits, want));
+            d->ks_digits_bytes = want;
+        }
+        ksm::launch(d->p, K, w, cnt, ext, flat_out, d->ks_limbs, d->ks_digits, d->ks_mfma_split, d->cus, stream);
+        return;
+    }
     if (nld > 0 && d->ks_sliced_ok && cnt >= d->ks_sliced_min) {
         kss::launch(d->p, K, w, cnt, ext, flat_out, d->ks_slice, d->ks_gates, stream);
         return;
