@@ -162,7 +162,7 @@ def roofline(p, stats, gate_rate, pmc):
                          "gates_per_s": br_gate_rate, "avg_launch_ms": br_avg_ms},
         "keyswitch": {"algorithmic_bytes_per_gate": ksk_b, "model_GBps": ks_gate_rate * ksk_b / 1e9,
                       "gates_per_s": ks_gate_rate, "avg_launch_ms": ks_avg_ms,
-                      "note": "model_GBps = streaming-model bytes x rate; the rows are served from L2 / Infinity Cache (profiles/traffic.json: keyswitch_sliced)"}}
+                      "note": "model_GBps = streaming-model bytes x rate; the key switch runs as an int8 MFMA product whose B stream is served from L2 / Infinity Cache (profiles/traffic.json: keyswitch)"}}
     return out
 
 

@@ -77,8 +77,10 @@ public:
     void set_force_generic(bool v) { force_generic_ = v; }
     // Maximum gate instances per launch (bounds the scratch buffers).
     void set_chunk(size_t items);
-    // Named tuning knobs: "chunk", "force_generic", "ks_sliced_min" (gate instances per launch from which
-    // the hand-scheduled key switch is used; default 576), "ks_gates" (its gate instances per workgroup:
+    // Named tuning knobs: "chunk", "force_generic", "ks_mfma_min" (gate instances per launch from which the key switch runs
+    // as an int8 product on the MFMA pipe, keyswitch_mfma.hip; default 64), "ks_mfma_split" (workgroups its walk is cut into
+    // per tile: 1, 2, 4, 8, or 0 = by launch size), "ks_sliced_min" (gate instances per launch from which, below that or
+    // with it disabled, the hand-scheduled walk is used; default 576), "ks_gates" (its gate instances per workgroup:
     // 4, 8, 16, 32, or 0 = by launch size), "ks_slice" (coefficients per launch of it, 0 = whole walk),
     // "ks_batch_min" (same threshold for the compiler-scheduled gate-batched kernel, the cross-check),
     // "ks_split_max" (workgroups the per-gate key switch may cut one gate's walk into when a launch holds only a

@@ -20,7 +20,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pass*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        short = "BR" if "blind_rotate" in k else ("KS" if "keyswitch" in k else None)
+        short = "BR" if "blind_rotate" in k else ("KS" if ("keyswitch" in k or "k_ksm_gemm" in k) else None)
         if short: agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
     for k in sorted(agg):

@@ -21,7 +21,7 @@ gates = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 key = sys.argv[4] if len(sys.argv) > 4 else "w1x64-radix8-onelimb"
 # FP64 instructions per gate and CMux step, counted in the kernels' ISA (scripts/isa_count.py)
-KERNELS = {"w1x64-radix8-onelimb": ("k_blind_rotate_w1<3,7,guard>", 2561), "w2x64-radix8-registers": ("k_blind_rotate_w2<3,7>", 3368)}
+KERNELS = {"w1x64-radix8-onelimb": ("k_blind_rotate_w1b<3,7,guard on 1 coefficient in 4>", 2493), "w2x64-radix8-registers": ("k_blind_rotate_w2<3,7>", 3368)}
 vals = {}
 for line in open(summary):
     m = re.match(r"(BR|KS) (\S+)\s+n=(\d+) avg=([0-9.e+-]+)", line)
@@ -52,12 +52,23 @@ out.update({
         "shader_cycles_per_gate_step": vals[("BR", "GRBM_GUI_ACTIVE")] / 8 / (gates * steps),
         "effective_clock_GHz_note": "GRBM_GUI_ACTIVE / 8 XCDs = %.3e shader cycles per launch (MI355X_MICROARCH.md, DVFS give-back: effective clock = that / kernel wall time)" % (vals[("BR", "GRBM_GUI_ACTIVE")] / 8),
     },
-    "keyswitch_sliced": {
-        "kernel": "k_keyswitch_sliced<G>", "pmc_summary": rel, "gates_per_launch": gates,
+    "keyswitch": {
+        "kernel": "k_ksm_gemm (int8 MFMA product)", "pmc_summary": rel, "gates_per_launch": gates,
         "FETCH_SIZE_KB_avg": vals[("KS", "FETCH_SIZE")], "WRITE_SIZE_KB_avg": vals[("KS", "WRITE_SIZE")],
         "hbm_bytes_per_launch": hbm("KS"),
         "l2_hit_rate": vals[("KS", "TCC_HIT_sum")] / (vals[("KS", "TCC_HIT_sum")] + vals[("KS", "TCC_MISS_sum")]),
     },
 })
+# the rocprofv3 --kernel-trace --stats average of the same kernel (primary bench leg alone), if the caller names the file
+for a in sys.argv[5:]:
+    if a.startswith("stats="):
+        import csv
+        f = a[6:]
+        for row in csv.DictReader(open(f)):
+            if "k_blind_rotate_w1" in row["Name"] and "prologue" not in row["Name"]:
+                out[key]["rocprof_avg_launch_ms"] = float(row["AverageNs"]) * 1e-6
+                out[key]["rocprof_calls"] = int(row["Calls"])
+                out[key]["rocprof_stats"] = os.path.relpath(os.path.abspath(f), ROOT) + " (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs none)"
+                break
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out[key], indent=1))

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-3 measurement set on one MI355X (run through gpurun from the repo root; stages keep each call under gpurun's limit):
+#   driver: the driver's bench command (all legs) -> the JSON line
+#   stats:  the primary leg alone, then the whole default command, under rocprofv3 --kernel-trace --stats
+#   pmc:    PMC passes over the blind-rotation / key-switch microbenchmark
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/r3_meas
+mkdir -p $OUT
+for stage in "$@"; do
+case $stage in
+driver)
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err
+  echo "driver command done"; tail -c 300 $OUT/bench_driver_cmd.json; echo ;;
+stats)
+  rm -rf $OUT/stats_add16 $OUT/stats_all
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_add16 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs none > $OUT/add16_rocprof.json 2> $OUT/add16_rocprof.err
+  find $OUT/stats_add16 -name "*kernel_stats.csv" | head -3
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/all_rocprof.json 2> $OUT/all_rocprof.err
+  find $OUT/stats_all -name "*kernel_stats.csv" | head -3 ;;
+pmc)
+  rm -rf $OUT/pmc
+  bash scripts/pmc_passes.sh $OUT/pmc python3 scripts/br_bench.py 8192 > $OUT/pmc.log 2>&1 || echo "pmc failed"
+  tail -50 $OUT/pmc/summary.txt || true ;;
+esac
+done
