@@ -181,22 +181,51 @@ __device__ __forceinline__ void swap_dwords(unsigned& lo, unsigned& hi, int lane
     }
 }
 
+// Lane bit 3 has no swap instruction.  As two DPP moves with bank masks the exchange costs a register copy on top (the
+// second move needs the first one's overwritten source): 3 instructions per dword pair.  v_cndmask_b32 takes a DPP source
+// itself -- new_hi = set ? hi : lo[lane ^ 8], new_lo = set ? hi[lane ^ 8] : lo with set = lane bit 3, VCC flipped in between
+// by the scalar unit -- 2 per pair, into fresh registers.  Four dwords (one double2) per block; the s_nop covers the
+// VALU-write -> DPP-read wait states the assembler does not insert inside an asm block.
+__device__ __forceinline__ void swap4_bit3(unsigned (&a)[4], unsigned (&b)[4]) {
+    unsigned na0, na1, na2, na3, nb0, nb1, nb2, nb3;
+    asm volatile(
+        "s_mov_b32 vcc_lo, 0xff00ff00\n\t"
+        "s_mov_b32 vcc_hi, 0xff00ff00\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_dpp %4, %8, %12, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %5, %9, %13, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %6, %10, %14, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %7, %11, %15, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %0, %12, %8, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %13, %9, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %2, %14, %10, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %15, %11, vcc row_ror:8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(na0), "=&v"(na1), "=&v"(na2), "=&v"(na3), "=&v"(nb0), "=&v"(nb1), "=&v"(nb2), "=&v"(nb3)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3])
+        : "vcc");
+    a[0] = na0, a[1] = na1, a[2] = na2, a[3] = na3;
+    b[0] = nb0, b[1] = nb1, b[2] = nb2, b[3] = nb3;
+}
+
 template <int B>
 __device__ __forceinline__ void bitswap(double2 (&x)[8], int lane) {
     constexpr int m = 1 << (B % 3);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         if (r & m) continue;
-        unsigned a0 = (unsigned)__double2loint(x[r].x), a1 = (unsigned)__double2hiint(x[r].x);
-        unsigned a2 = (unsigned)__double2loint(x[r].y), a3 = (unsigned)__double2hiint(x[r].y);
-        unsigned b0 = (unsigned)__double2loint(x[r | m].x), b1 = (unsigned)__double2hiint(x[r | m].x);
-        unsigned b2 = (unsigned)__double2loint(x[r | m].y), b3 = (unsigned)__double2hiint(x[r | m].y);
-        swap_dwords<B>(a0, b0, lane);
-        swap_dwords<B>(a1, b1, lane);
-        swap_dwords<B>(a2, b2, lane);
-        swap_dwords<B>(a3, b3, lane);
-        x[r] = make_double2(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)a3, (int)a2));
-        x[r | m] = make_double2(__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2));
+        unsigned a[4] = {(unsigned)__double2loint(x[r].x), (unsigned)__double2hiint(x[r].x), (unsigned)__double2loint(x[r].y),
+                         (unsigned)__double2hiint(x[r].y)};
+        unsigned b[4] = {(unsigned)__double2loint(x[r | m].x), (unsigned)__double2hiint(x[r | m].x), (unsigned)__double2loint(x[r | m].y),
+                         (unsigned)__double2hiint(x[r | m].y)};
+        if constexpr (B == 3) {
+            swap4_bit3(a, b);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) swap_dwords<B>(a[q], b[q], lane);
+        }
+        x[r] = make_double2(__hiloint2double((int)a[1], (int)a[0]), __hiloint2double((int)a[3], (int)a[2]));
+        x[r | m] = make_double2(__hiloint2double((int)b[1], (int)b[0]), __hiloint2double((int)b[3], (int)b[2]));
     }
 }
 // register index <-> lane bits 3..5 (what the first LDS transpose does)

@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <stdexcept>
 
 namespace ieache {
@@ -98,10 +99,10 @@ __global__ __launch_bounds__(256) void k_ksm_init(DevKeys K, WorkDesc W, const T
 }
 
 // ---- the product ----
-// grid: (coefficient block cb fastest, then K split, then block of 512 gates); 4 independent waves per workgroup.
+// grid: one workgroup (4 independent waves) per (coefficient block, K split, block of 512 gates); the order is an L2 matter, see below.
 __global__ __launch_bounds__(64 * kWgWaves) void k_ksm_gemm(const v4i* __restrict__ limbs, const unsigned long long* __restrict__ dig4,
-                                                            Torus32* const* __restrict__ out_ptr, int64_t items, int64_t gpad, int32_t N,
-                                                            int32_t ncb, int32_t stride, int32_t ksplit) {
+                                                            Torus32* const* __restrict__ out_ptr, int64_t items, int64_t gpad, int64_t gblocks,
+                                                            int32_t N, int32_t ncb, int32_t stride, int32_t ksplit, int32_t xcd_map) {
     __shared__ v4i lut[256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,10 +113,24 @@ __global__ __launch_bounds__(64 * kWgWaves) void k_ksm_gemm(const v4i* __restric
         lut[tid] = e;
     }
     __syncthreads();
-    const int32_t cb = blockIdx.x % ncb;
-    const int32_t rest = blockIdx.x / ncb;
-    const int32_t ks = rest % ksplit;
-    const int64_t gbase = (int64_t)(rest / ksplit) * kWgGates + (int64_t)wave * kWaveGates;
+    // Which (coefficient block, K split) stream and which block of 512 gates this workgroup takes.  Default: streams
+    // fastest, so that every XCD (workgroups are dealt round-robin over them) walks all streams and each pulls the whole
+    // 84 MB through its L2 (measured: L2 hit rate 59 %, 0.55 GB of fetch per 8 192 gates).  xcd_map (IEACHE_KS_XCD=1) gives
+    // each XCD its own eighth of the streams instead, walked by all its CUs together -- fewer bytes, but MEASURED SLOWER
+    // (0.77 against 0.66 ms per 8 192 gates: thirty-two CUs hammering the same few L2 channels); kept as the A/B partner.
+    const int32_t streams = ncb * ksplit;
+    int32_t st;
+    int64_t gblk;
+    if (xcd_map && streams % 8 == 0) {
+        const int32_t x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        st = x + 8 * (int32_t)(j / gblocks);
+        gblk = j % gblocks;
+    } else {
+        st = blockIdx.x % streams;
+        gblk = blockIdx.x / streams;
+    }
+    const int32_t cb = st % ncb, ks = st / ncb;
+    const int64_t gbase = gblk * kWgGates + (int64_t)wave * kWaveGates;
     if (gbase >= items) return;  // whole wave past the launch (after the only barrier)
     const int m = lane & 31, grp = lane >> 5;
     const int32_t i4_0 = (N / 4 / ksplit) * ks, i4_1 = i4_0 + N / 4 / ksplit;
@@ -133,38 +148,36 @@ __global__ __launch_bounds__(64 * kWgWaves) void k_ksm_gemm(const v4i* __restric
     unsigned long long d64[4], d64n[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) d64n[t] = dg[(size_t)i4_0 * gpad + t * 32];
-    v4i bn[4];
-    {
-        const v4i* bp = limbs + ((size_t)(4 * i4_0) * ncb + cb) * 256 + lane;
+    // B fragments are requested FOUR coefficients ahead (one wave per SIMD has nothing else to hide an L2 miss behind):
+    // buffer c holds coefficient 4 i4 + c and is refilled with 4 (i4 + 1) + c right after its products are issued
+    v4i bq[4][4];
+    const v4i* bp0 = limbs + (size_t)cb * 256 + lane;
 #pragma unroll
-        for (int l = 0; l < 4; l++) bn[l] = bp[l * 64];
-    }
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int l = 0; l < 4; l++) bq[c][l] = bp0[(size_t)(4 * i4_0 + c) * ncb * 256 + l * 64];
 #pragma unroll 1
     for (int32_t i4 = i4_0; i4 < i4_1; i4++) {
 #pragma unroll
         for (int t = 0; t < 4; t++) d64[t] = d64n[t];
-        if (i4 + 1 < i4_1) {
+        const bool more = i4 + 1 < i4_1;
+        if (more) {
 #pragma unroll
             for (int t = 0; t < 4; t++) d64n[t] = dg[(size_t)(i4 + 1) * gpad + t * 32];
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            v4i b[4];
-#pragma unroll
-            for (int l = 0; l < 4; l++) b[l] = bn[l];
-            const int32_t inext = 4 * i4 + c + 1;
-            if (inext < 4 * i4_1) {  // next coefficient's fragments, requested before this one's products
-                const v4i* bp = limbs + ((size_t)inext * ncb + cb) * 256 + lane;
-#pragma unroll
-                for (int l = 0; l < 4; l++) bn[l] = bp[l * 64];
-            }
             v4i a[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) a[t] = lut[(unsigned)(d64[t] >> (16 * c + sh0)) & 0xFFu];
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int l = 0; l < 4; l++) acc[t][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t], b[l], acc[t][l], 0, 0, 0);
+                for (int l = 0; l < 4; l++) acc[t][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t], bq[c][l], acc[t][l], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int l = 0; l < 4; l++) bq[c][l] = bp0[(size_t)(4 * (i4 + 1) + c) * ncb * 256 + l * 64];
+            }
         }
     }
     // epilogue: D[row][col] of a 32x32 tile sits in register v of lane: col = lane % 32, row = 8 (v / 4) + 4 (lane / 32) + v % 4
@@ -227,10 +240,11 @@ int launch(const Params& p, const DevKeys& K, const WorkDesc& W, int64_t items, 
         }
     }
     if ((p.N / 4) % ksplit != 0) throw std::invalid_argument("key-switch K split does not divide N / 4");
+    static const int32_t xcd_map = getenv("IEACHE_KS_XCD") ? atoi(getenv("IEACHE_KS_XCD")) : 0;  // measurement aid, see k_ksm_gemm
     hipLaunchKernelGGL(k_ksm_digits, dim3((unsigned)(p.N / 64), (unsigned)(gpad / 64)), dim3(256), 0, stream, ext, dig4, items, gpad, p.N);
     hipLaunchKernelGGL(k_ksm_init, dim3((unsigned)items), dim3(256), 0, stream, K, W, ext, flat_out, out_ptr);
     hipLaunchKernelGGL(k_ksm_gemm, dim3((unsigned)(gblocks * ncb * ksplit)), dim3(64 * kWgWaves), 0, stream,
-                       reinterpret_cast<const v4i*>(d_limbs), dig4, out_ptr, items, gpad, p.N, ncb, p.lwe_stride(), ksplit);
+                       reinterpret_cast<const v4i*>(d_limbs), dig4, out_ptr, items, gpad, gblocks, p.N, ncb, p.lwe_stride(), ksplit, xcd_map);
     return 3;
 }
 
