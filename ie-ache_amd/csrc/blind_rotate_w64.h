@@ -61,6 +61,9 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //        of mid-size launches   37 guard on every coefficient
 //     38 k_blind_rotate_wide4: 2L waves per gate, four output waves on half the rows each, no barrier B -- the default of
 //        narrow launches   39 guard on every coefficient
+//     measured and NOT faster (kept as the A/B partners): 40 k_blind_rotate_wide on one limb built for two workgroups per CU
+//     (186 spilled registers), 41 k_blind_rotate_wide4b (the same for wide4: 5.7 ms at 512 gates against w2r's 5.2),
+//     42 k_blind_rotate_w1b with the rows software-pipelined (next row's digits under this row's last transpose: -1 %)
 int32_t default_variant();
 constexpr int32_t kVariantWide = 7;
 constexpr int32_t kVariantOneLimb = 13;

@@ -208,7 +208,8 @@ __device__ __forceinline__ void swap4_bit3(unsigned (&a)[4], unsigned (&b)[4]) {
     b[0] = nb0, b[1] = nb1, b[2] = nb2, b[3] = nb3;
 }
 
-template <int B>
+// SW3 = 0: round 2's bit-3 exchange (two DPP moves and a copy), kept for k_blind_rotate_w1 as the A/B partner
+template <int B, int SW3 = 1>
 __device__ __forceinline__ void bitswap(double2 (&x)[8], int lane) {
     constexpr int m = 1 << (B % 3);
 #pragma unroll
@@ -218,7 +219,7 @@ __device__ __forceinline__ void bitswap(double2 (&x)[8], int lane) {
                          (unsigned)__double2hiint(x[r].y)};
         unsigned b[4] = {(unsigned)__double2loint(x[r | m].x), (unsigned)__double2hiint(x[r | m].x), (unsigned)__double2loint(x[r | m].y),
                          (unsigned)__double2hiint(x[r | m].y)};
-        if constexpr (B == 3) {
+        if constexpr (B == 3 && SW3 == 1) {
             swap4_bit3(a, b);
         } else {
 #pragma unroll
@@ -229,8 +230,9 @@ __device__ __forceinline__ void bitswap(double2 (&x)[8], int lane) {
     }
 }
 // register index <-> lane bits 3..5 (what the first LDS transpose does)
+template <int SW3 = 1>
 __device__ __forceinline__ void xlane_hi(double2 (&x)[8], int lane) {
-    bitswap<3>(x, lane);
+    bitswap<3, SW3>(x, lane);
     bitswap<4>(x, lane);
     bitswap<5>(x, lane);
 }
@@ -257,8 +259,10 @@ struct NoHook {
 };
 // MID: called once the first inter-pass twiddles are consumed (their 32 VGPRs are free from there on): the place to
 // request data the caller needs right after the transform
-template <bool WSYNC, int XLANE = 0, int ILV = 0, class MID = NoHook, bool MID_LATE = false>
-__device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R, MID mid = MID()) {
+// POST: called once the reads of the last (lane-low) transpose are issued and before their data is used: work that does not
+// depend on them runs under that LDS round trip
+template <bool WSYNC, int XLANE = 0, int ILV = 0, class MID = NoHook, bool MID_LATE = false, int SW3 = 1, class POST = NoHook>
+__device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R, MID mid = MID(), POST post = POST()) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
     const int blk = hi * 72 + lo;  // (h, l) = (lane>>3, lane&7)
@@ -308,7 +312,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
 #pragma unroll
     for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
     if (XLANE & 1) {
-        xlane_hi(x, lane);                                          // reg k0 <-> lane bits 3..5: lane = (k0, p0), reg = p1
+        xlane_hi<SW3>(x, lane);                                     // reg k0 <-> lane bits 3..5: lane = (k0, p0), reg = p1
     } else {
 #pragma unroll
         for (int k0 = 0; k0 < 8; k0++) sT[own + 72 * k0] = x[k0];   // element (k0, p1, p0), lane = (p1, p0)
@@ -334,6 +338,11 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
         const int rd = hi * 72 + lo * 9;                            // lane = (k0, k1)
 #pragma unroll
         for (int q = 0; q < 8; q++) x[q] = sT[rd + q];
+        if (!std::is_same<POST, NoHook>::value) {
+            __builtin_amdgcn_sched_barrier(0);
+            post();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         tile_sync<WSYNC>();
     }
     dft8<false>(x);                          // over p0 -> k2 ; lane = 8*k0 + k1
@@ -839,9 +848,9 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
                 auto req = [&]() {
                     load_bk_block<BUF>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
                 };
-                fft512_forward<true, XLANE, 0, decltype(req), EARLYB == 3>(x, sT, lane, R, req);
+                fft512_forward<true, XLANE, 0, decltype(req), EARLYB == 3, 0>(x, sT, lane, R, req);
             } else {
-                fft512_forward<true, XLANE, 0>(x, sT, lane, R);
+                fft512_forward<true, XLANE, 0, NoHook, false, 0>(x, sT, lane, R);
             }
             if (EARLYB == 0) {
                 load_bk_block<BUF>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);  // -> output polynomial 1
@@ -1018,6 +1027,61 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
                                 : make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
                                                fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
         };
+        if (XMIX == 3) {
+            // software pipeline over the 2L rows: the digits / conversion / twist of row + 1 (and, before the first row of
+            // polynomial 1, its decomposition) run under row's lane-low transpose, into a second set of registers
+            auto prep = [&](double2 (&x)[8], const int sh) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);
+                    const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
+                    x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                                  : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                }
+            };
+            double2 xa[8], xb[8];
+            decompose(pb0);
+            prep(xa, 32 - BGBIT);
+            auto row_body = [&](auto row_c, double2 (&x)[8], double2 (&xn)[8]) {
+                constexpr int row = decltype(row_c)::value;
+                constexpr bool FIRST = row == 0;
+                const int brow = bki + row * kRowBytes;
+                double2 bA[8], bB[8];
+                load_bk_block<true>(bA, bk_rsrc, lane16, brow, bkf1);
+                __builtin_amdgcn_sched_barrier(0);
+                auto next = [&]() {
+                    if (row + 1 < 2 * L) {
+                        if (row + 1 == L) decompose(pb0 + 4096u);
+                        constexpr int q = (row + 1) >= L ? row + 1 - L : row + 1;
+                        prep(xn, 32 - (q + 1) * BGBIT);
+                    }
+                };
+                fft512_forward<true, 1, 0, NoHook, false, 1, decltype(next)>(x, sT, lane, R, NoHook(), next);
+                load_bk_block<true>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    s[0][k] = FIRST ? cmulx<false>(x[k], bA[k])
+                                    : make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[0][k].x)),
+                                                   fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[0][k].y)));
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    s[1][k] = FIRST ? cmulx<false>(x[k], bB[k])
+                                    : make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
+                                                   fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
+            };
+            row_body(std::integral_constant<int, 0>{}, xa, xb);
+            row_body(std::integral_constant<int, 1>{}, xb, xa);
+            if (L > 2) row_body(std::integral_constant<int, (L > 2 ? 2 : 0)>{}, xa, xb);
+            if (L > 2) {
+                row_body(std::integral_constant<int, (L > 2 ? 3 : 0)>{}, xb, xa);
+                row_body(std::integral_constant<int, (L > 2 ? 4 : 0)>{}, xa, xb);
+                row_body(std::integral_constant<int, (L > 2 ? 5 : 0)>{}, xb, xa);
+            } else {
+                row_body(std::integral_constant<int, 2>{}, xa, xb);
+                row_body(std::integral_constant<int, (L > 2 ? 0 : 3)>{}, xb, xa);
+            }
+        } else {
         decompose(pb0);
         digit_row(32 - BGBIT, bki, std::true_type{}, std::false_type{});
         if (XMIX == 2) {
@@ -1039,6 +1103,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
 #pragma unroll 1
             for (int row = L; row < 2 * L; row++)
                 digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::integral_constant<bool, XMIX == 1>{});
+        }
         }
         fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
 #pragma unroll
@@ -2274,6 +2339,7 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         case 20: IEACHE_W1B(2, 1) return;   // polynomial 1's forward transposes through LDS
         case 21: IEACHE_W1B(2, 2) return;   // every second row's
         case 22: IEACHE_W1B(0, 0) return;   // no guard arithmetic (measurement)
+        case 29: IEACHE_W1B(2, 3) return;   // rows software-pipelined: the next row's digits / twist under this row's last transpose
         default: break;
     }
 #undef IEACHE_W1B
