@@ -606,7 +606,7 @@ void Evaluator::init() {
         // (k_blind_rotate_w2, "exact_fft": 2 waves per gate, 35.8 KB of LDS -> 4 per CU)
         resident_gates_ = 8 * cus;
         d_->one_limb_min = cus + 1;  // everything the latency kernel does not take
-        d_->two_wave_max = 4 * cus;
+        d_->two_wave_max = 5 * cus;  // measured crossover with one wave per gate: 1 216 gates 8.6 against 10.0 ms, 1 400 gates 10.8 against 10.1
         if (const char* e = getenv("IEACHE_TWO_WAVE_MAX")) d_->two_wave_max = atoll(e);
         if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
         if (const char* e = getenv("IEACHE_ONE_LIMB_MIN")) d_->one_limb_min = atoll(e);
