@@ -35,7 +35,7 @@ int gates_per_workgroup_w1();
 size_t twiddle_table_elems();
 void build_twiddle_table(double2* d_tw, hipStream_t stream);
 // Kernel variants ("br_variant" / IEACHE_BR_VARIANT; all produce identical bits).  0 lets the EVALUATOR choose by launch
-// size (evaluator.hip: <= one gate per CU -> 38, <= 4 per CU -> 36, above -> 31; "exact_fft": 7 / 0); passed to launch()
+// size (evaluator.hip: <= one gate per CU -> 38, <= 2 per CU -> 43, <= 5 per CU -> 36, above -> 31; "exact_fft": 7 / 0); passed to launch()
 // itself, 0 is the two-limb two-wave kernel.
 //   two limbs (exact by construction), two waves per gate -- k_blind_rotate_w2:
 //     0  wave-local sync, the forward transforms' lane-high transpose cross-lane (v_permlane*_swap / DPP), every other
@@ -61,6 +61,8 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //        of mid-size launches   37 guard on every coefficient
 //     38 k_blind_rotate_wide4: 2L waves per gate, four output waves on half the rows each, no barrier B -- the default of
 //        narrow launches   39 guard on every coefficient
+//     43 k_blind_rotate_w4r: four waves per gate, rows split 2 : 1 : 2 : 1, one hand-over per step -- the default of launches
+//        of one to two gates per CU (4.4 ms against w2r's 5.2)   44 guard on every coefficient
 //     measured and NOT faster (kept as the A/B partners): 40 k_blind_rotate_wide on one limb built for two workgroups per CU
 //     (186 spilled registers), 41 k_blind_rotate_wide4b (the same for wide4: 5.7 ms at 512 gates against w2r's 5.2),
 //     42 k_blind_rotate_w1b with the rows software-pipelined (next row's digits under this row's last transpose: -1 %)
@@ -69,6 +71,7 @@ constexpr int32_t kVariantWide = 7;
 constexpr int32_t kVariantOneLimb = 13;
 constexpr int32_t kVariantOneLimbDefault = 31;  // k_blind_rotate_w1b, guard on one coefficient in four (round 3)
 constexpr int32_t kVariantOneLimbTwoWaves = 36;     // k_blind_rotate_w2r (round 3; round 2's k_blind_rotate_w2s = 20)
+constexpr int32_t kVariantOneLimbFourWaves = 43;    // k_blind_rotate_w4r (round 3): launches of one to two gates per CU
 constexpr int32_t kVariantWideOneLimb = 22;
 constexpr int32_t kVariantWideHandoverOneLimb = 38;  // k_blind_rotate_wide4 (round 3; round 2's k_blind_rotate_wide on one limb = 24)
 

@@ -1324,6 +1324,191 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2r(DevKeys K, const do
     }
 }
 
+// ---- K3 (+K4), one to two gates per CU, round 3: FOUR waves per gate, the rows split 2 : 1 : 2 : 1 ----
+// Launches of 257 .. 512 gate instances leave every SIMD a single wave under k_blind_rotate_w2r, and a lone wave issues a
+// vector instruction only every 6-7 cycles.  Here a gate is one 256-thread workgroup (two per CU: two waves per SIMD):
+//   wave 2p     ("heavy", polynomial p): digits 0 .. L-2 of accumulator polynomial p -- L-1 forward transforms, each
+//               multiplied with BOTH output blocks of its BK row (two partial spectrum sums, as in k_blind_rotate_w1b);
+//   wave 2p + 1 ("light"): digit L-1 the same way, then the inverse transform of OUTPUT polynomial p.
+// One hand-over per step: every wave passes on the partial sums it does not invert -- through its own (idle) tile and,
+// for the heavy waves' second sum, one of two extra 8 KiB slots -- barrier, the light waves add the three sums they
+// receive, inverse-transform (scratch: the tile they have just emptied, which nobody else reads), round and ds_add_u32
+// into "their" accumulator polynomial, barrier.  Arithmetic differs from the other kernels only in the order of exact-
+// after-rounding FP64 sums.
+// dynamic LDS: acc [2][1024] int32 | sT [4][kTile] double2 | X [2][8][64] double2 | tw [kTwElems] double2   (70 656 B -> 2 per CU)
+template <int L, int BGBIT, int GUARD>
+__global__ __launch_bounds__(256, 2) void k_blind_rotate_w4r(DevKeys K, const double2* __restrict__ bkf1,
+                                                            const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                            int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
+                                                            unsigned* guard, const double2* __restrict__ gtw, int32_t flip_period) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int32_t* acc = reinterpret_cast<int32_t*>(smem);
+    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)2 * kN * 4);
+    double2* sX = sT_all + 4 * kTile;
+    double2* sTw = sX + 2 * 8 * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // The two workgroups that share a CU (observed: workgroup i and i + #CUs) swap the heavy and the light role within each
+    // wave pair, so that every SIMD hosts one heavy and one light wave instead of two of a kind waiting for each other's phase.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) ^ (int)((blockIdx.x / (unsigned)flip_period) & 1u);
+    const int pol = wave >> 1;
+    const bool light = wave & 1;
+    double2* sT = sT_all + wave * kTile;
+    const int64_t item = (int64_t)blockIdx.x;
+    const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    load_twiddles(sTw, gtw, tid, 256);
+    const LaneRoots R = make_roots(sTw, lane);
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+#pragma unroll
+        for (int r = 0; r < 2; r++) dst[256 * r + tid] = src[256 * r + tid];
+    }
+    __syncthreads();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+    double dev_max = 0.0;
+    constexpr int kRowBytes = 2 * kM * (int)sizeof(double2), kStepBytes = 2 * L * kRowBytes;
+    const __amdgpu_buffer_rsrc_t bk_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(bkf1), (short)0, K.n * kStepBytes, 0x00020000);
+    const int lane16 = lane * (int)sizeof(double2);
+    const unsigned char* accb = reinterpret_cast<const unsigned char*>(acc);
+    const uint32_t pb = (uint32_t)pol * (kN * 4);
+    const int32_t* accp = acc + pol * kN;
+    uint32_t* accu = reinterpret_cast<uint32_t*>(acc) + pol * kN;
+    const int q0 = light ? L - 1 : 0, q1 = light ? L : (L > 1 ? L - 1 : 1);  // this wave's digits [q0, q1)
+    // where the partial sums go: `keep` stays (light waves: the output they invert), `give0` / `give1` are handed over
+    //   wave 0: s[0] -> tile 0 (for wave 1), s[1] -> slot 0 (for wave 3)      wave 1: s[1] -> tile 1 (for wave 3)
+    //   wave 2: s[1] -> tile 2 (for wave 3), s[0] -> slot 1 (for wave 1)      wave 3: s[0] -> tile 3 (for wave 1)
+    double2* slot_extra = sX + pol * (8 * 64);
+    const double2* in_a = light ? (pol == 0 ? sT_all + 0 * kTile : sX + 0 * (8 * 64)) : nullptr;        // wave 1: tile 0 ; wave 3: slot 0
+    const double2* in_b = light ? (pol == 0 ? sX + 1 * (8 * 64) : sT_all + 1 * kTile) : nullptr;        // wave 1: slot 1 ; wave 3: tile 1
+    const double2* in_c = light ? (pol == 0 ? sT_all + 3 * kTile : sT_all + 2 * kTile) : nullptr;       // wave 1: tile 3 ; wave 3: tile 2
+    double2* scratch = sT_all + (pol == 0 ? 0 : 2) * kTile;  // the heavy partner's tile: after the hand-over only this light wave reads it
+
+    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
+        if (a == 0) continue;  // workgroup-uniform
+        const int bki = i * kStepBytes + pol * L * kRowBytes;  // the rows of this wave's polynomial
+        double2 s[2][8];
+        uint32_t v0[8], v1[8];
+        const uint32_t jb4 = ((uint32_t)(lane - a) & (2 * kN - 1)) << 2;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t t = jb4 + 256u * r;
+            const uint32_t o0 = (t & 4092u) | pb, o1 = o0 ^ 2048u;
+            const int32_t m0 = __builtin_amdgcn_sbfe((int32_t)t, 12, 1), m1 = __builtin_amdgcn_sbfe((int32_t)(t + 2048u), 12, 1);
+            const uint32_t rv0 = *reinterpret_cast<const uint32_t*>(accb + o0), rv1 = *reinterpret_cast<const uint32_t*>(accb + o1);
+            const uint32_t pv0 = (uint32_t)accp[64 * r + lane], pv1 = (uint32_t)accp[64 * r + lane + kM];
+            v0[r] = ((rv0 ^ (uint32_t)m0) + ((dec_offset - pv0) - (uint32_t)m0)) ^ dec_offset;
+            v1[r] = ((rv1 ^ (uint32_t)m1) + ((dec_offset - pv1) - (uint32_t)m1)) ^ dec_offset;
+        }
+        auto digit_row = [&](const int sh, const int brow, auto first) {
+            constexpr bool FIRST = decltype(first)::value;
+            double2 x[8], bA[8], bB[8];
+            load_bk_block<true>(bA, bk_rsrc, lane16, brow, bkf1);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);
+                const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
+                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft512_forward<true, 1, 0>(x, sT, lane, R);
+            load_bk_block<true>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[0][k] = FIRST ? cmulx<false>(x[k], bA[k])
+                                : make_double2(fma(x[k].x, bA[k].x, fma(-x[k].y, bA[k].y, s[0][k].x)),
+                                               fma(x[k].x, bA[k].y, fma(x[k].y, bA[k].x, s[0][k].y)));
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                s[1][k] = FIRST ? cmulx<false>(x[k], bB[k])
+                                : make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
+                                               fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
+        };
+        digit_row(32 - (q0 + 1) * BGBIT, bki + q0 * kRowBytes, std::true_type{});
+#pragma unroll 1
+        for (int q = q0 + 1; q < q1; q++) digit_row(32 - (q + 1) * BGBIT, bki + q * kRowBytes, std::false_type{});
+        // hand-over: the sum for this wave's own polynomial's output goes to (or stays with) the light wave of that polynomial
+        double2 y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double2 own = pol ? s[1][k] : s[0][k], other = pol ? s[0][k] : s[1][k];
+            if (light) {
+                y[k] = own;
+                sT[k * 64 + lane] = other;          // for the other polynomial's light wave
+            } else {
+                sT[k * 64 + lane] = own;            // for this polynomial's light wave
+                slot_extra[k * 64 + lane] = other;  // for the other polynomial's light wave
+            }
+        }
+        __syncthreads();
+        if (light) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double2 za = in_a[k * 64 + lane], zb = in_b[k * 64 + lane], zc = in_c[k * 64 + lane];
+                y[k] = cadd(cadd(y[k], za), cadd(zb, zc));
+            }
+            fft512_inverse<true, 0>(y, scratch, lane, R);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
+                double t0, t1;
+                if (r == 0) {
+                    if (watched) {
+                        const double zx = y[0].x * (1.0 / 512.0), zy = y[0].y * (1.0 / 512.0);
+                        t0 = zx + kMagic, t1 = zy + kMagic;
+                        dev_max = fmax(dev_max, fabs(zx - (t0 - kMagic)));
+                        dev_max = fmax(dev_max, fabs(zy - (t1 - kMagic)));
+                    } else {
+                        t0 = fma(y[0].x, 1.0 / 512.0, kMagic), t1 = fma(y[0].y, 1.0 / 512.0, kMagic);
+                    }
+                } else {
+                    const double2 z = cmulx<true>(y[r], untwist_reg(r));
+                    t0 = z.x + kMagic, t1 = z.y + kMagic;
+                    if (watched) {
+                        dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
+                        dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
+                    }
+                }
+                const int32_t j = 64 * r + lane;
+                __hip_atomic_fetch_add(&accu[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&accu[j + kM], (uint32_t)__double2loint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        __syncthreads();  // accumulator complete; every handed-over sum consumed; the tiles are scratch again
+    }
+    if (GUARD && light) {
+        float m = (float)dev_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
+            if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
+        }
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = tid; j <= kN; j += 256)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+#pragma unroll
+        for (int r = 0; r < 2; r++) dst[256 * r + tid] = src[256 * r + tid];
+    }
+}
+
 // ---- K3 (+K4), mid-size launches: two waves per gate instance on the ONE-limb spectrum ----
 // Between the latency kernel (a handful of gates) and k_blind_rotate_w1 (more gates than the chip holds one-per-SIMD-slot)
 // lie launches of a few hundred to ~1 000 gates: deep circuits at small batches, cloudd's batches.  One wave per gate
@@ -2223,6 +2408,17 @@ static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream
     }
 }
 
+// workgroups i and i + period are taken to share a CU: the device's CU count (IEACHE_W4R_FLIP overrides; a huge value = never flip)
+static int32_t w4r_flip_period() {
+    static const int32_t v = [] {
+        if (const char* e = getenv("IEACHE_W4R_FLIP")) return atoi(e) > 0 ? atoi(e) : 1 << 30;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus > 0 ? cus : 256;
+    }();
+    return v;
+}
+
 template <int L, int BGBIT>
 static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const DevKeys& K, const double2* d_bkf1,
                             const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e,
@@ -2293,6 +2489,18 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_w1b"); \
         hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, __VA_ARGS__>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, \
                            st_acc, items, i0, i1, e, guard, gtw);                                                               \
+    }
+    if (sub == 30 || sub == 31) {  // round 3: four waves per gate, rows 2:1:2:1 (launches of one to two gates per CU); 31 = guard on every coefficient
+        const size_t lds4 = (size_t)(4 * kTile + 2 * 8 * 64 + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
+        static const bool attr_set =
+            hipFuncSetAttribute((const void*)k_blind_rotate_w4r<L, BGBIT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+            hipFuncSetAttribute((const void*)k_blind_rotate_w4r<L, BGBIT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_w4r");
+        if (sub == 30)
+            hipLaunchKernelGGL((k_blind_rotate_w4r<L, BGBIT, 2>), dim3((unsigned)items), dim3(256), lds4, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw, w4r_flip_period());
+        else
+            hipLaunchKernelGGL((k_blind_rotate_w4r<L, BGBIT, 1>), dim3((unsigned)items), dim3(256), lds4, stream, K, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw, w4r_flip_period());
+        return;
     }
     if (sub == 28) {  // round 3: k_blind_rotate_wide4 built for two workgroups per CU (launches of one to two gates per CU)
         const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;

@@ -90,7 +90,8 @@ public:
     // 2L-waves-per-gate kernel; default = the device's CU count, 0 = never), "br_variant",
     // "exact_fft" (1 = two-limb blind rotation always), "one_limb_min" (launches of at least this many gate
     // instances use the one-limb kernels; default: one per CU + 1), "two_wave_max" (of those, launches up to this many
-    // gate instances take two waves per gate, k_blind_rotate_w2s; default 4 per CU), "fft_guard_inject" (test hook: 1 makes
+    // gate instances take two waves per gate, k_blind_rotate_w2r; default 5 per CU), "four_wave_max" (launches up to this many
+    // take four waves per gate, k_blind_rotate_w4r; default 2 per CU), "fft_guard_inject" (test hook: 1 makes
     // the next call find the rounding guard tripped, so that it repeats itself on the two-limb kernels), "fft_audit" (see
     // fft_audit_counts), "fft_audit_inject" (test hook: 1 makes the next audit report a differing row).
     // Returns false for an unknown name or a value out of range.

@@ -525,6 +525,7 @@ struct Evaluator::Impl {
     bool exact_fft = false;      // "exact_fft": never use the one-limb kernel
     bool exact_once = false;     // set while a call is repeated after a guard trip
     int64_t one_limb_min = 0;    // launches of at least this many gate instances use the one-limb kernels
+    int64_t four_wave_max = 0;   // ... the four-waves-per-gate one (k_blind_rotate_w4r) up to this many (2 per CU),
     int64_t two_wave_max = 0;    // ... the two-waves-per-gate one up to this many (4 per CU: all resident at once), the one-wave one above
     double guard_max = 0;        // largest rounding deviation seen by the one-limb kernel (of 0.5)
     int64_t guard_reruns = 0;    // calls repeated on the two-limb kernel
@@ -606,6 +607,7 @@ void Evaluator::init() {
         // (k_blind_rotate_w2, "exact_fft": 2 waves per gate, 35.8 KB of LDS -> 4 per CU)
         resident_gates_ = 8 * cus;
         d_->one_limb_min = cus + 1;  // everything the latency kernel does not take
+        d_->four_wave_max = 2 * cus;
         d_->two_wave_max = 5 * cus;  // measured crossover with one wave per gate: 1 216 gates 8.6 against 10.0 ms, 1 400 gates 10.8 against 10.1
         if (const char* e = getenv("IEACHE_TWO_WAVE_MAX")) d_->two_wave_max = atoll(e);
         if (const char* e = getenv("IEACHE_BR_WIDE_MAX")) d_->br_wide_max = atoll(e);
@@ -753,6 +755,8 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->one_limb_min = value;
     } else if (name == "two_wave_max" && value >= 0) {
         d_->two_wave_max = value;
+    } else if (name == "four_wave_max" && value >= 0) {
+        d_->four_wave_max = value;
 
     } else if (name == "fft_audit" && value >= 0 && value <= (1 << 30)) {
         d_->fft_audit = (int32_t)value;
@@ -877,8 +881,10 @@ static void pick_br_variant(const Params& p, const Evaluator::Impl* d, int64_t c
             variant = (d->exact_fft || d->exact_once) ? w64::kVariantWide : w64::kVariantWideHandoverOneLimb;
             slice = w64::bara_stride(p);
         } else if (!d->exact_fft && !d->exact_once && cnt >= d->one_limb_min) {
-            // while every gate fits a two-wave slot, two waves per gate finish a step sooner than one
-            variant = cnt <= d->two_wave_max ? w64::kVariantOneLimbTwoWaves : w64::kVariantOneLimbDefault;
+            // one to two gates per CU: four waves per gate (two waves per SIMD); while every gate fits a two-wave slot, two
+            // waves per gate finish a step sooner than one
+            variant = cnt <= d->four_wave_max ? w64::kVariantOneLimbFourWaves
+                      : cnt <= d->two_wave_max ? w64::kVariantOneLimbTwoWaves : w64::kVariantOneLimbDefault;
         }
     } else if (d->exact_once && variant >= w64::kVariantOneLimb) {
         variant = 0;
