@@ -244,6 +244,8 @@ CLOUD_N630_CASES = (
     ("add16_in_32bit_word", 1, 32, (0, 0xBEEF, 4101), (0, 0x1234, 4102)),   # BASELINE configs[0]: 16-bit a+b, zero-extended in the 32-bit word
     ("sub32", 2, 32, (0, 0x1234ABCD, 4103), (0, 0x0FEDCBA9, 4104)),
     ("mul32", 4, 32, (0, 0xC0FFEE11, 4105), (0, 0x89ABCDEF, 4106)),
+    ("add64", 1, 64, (0, 0xFEDCBA9876543210, 4107), (0, 0x0123456789ABCDEF, 4108)),                    # sum = 2^64 - 1: every sum bit set, no carry out
+    ("sub32_borrow", 2, 32, (0, 0x0FEDCBA9, 4109), (0, 0x1234ABCD, 4110)),                               # a < b: two's complement result
 )
 CLOUD_N630_KEY_SEED, CLOUD_N630_NBIT_SEED = (314, 1592, 657), (2718, 2818)
 
@@ -289,6 +291,8 @@ def cloud_n630(only=None):
             val = tools.bits_to_int(tools.decrypt_bits(p, lwe_key, ref[:32 * nw]))
             exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 4: a * b}[op]
             assert val == exp, (name, hex(val), hex(exp))
+            if op == 2 and a < b:
+                exp = a - b  # what verif.c reads: two's complement (verif.c:733-789)
             out["cases"][name] = {"operator": op, "bits": bits, "a": a, "sign_a": sa, "seed_a": seed_a, "b": b, "sign_b": sb,
                                   "seed_b": seed_b, "cloud_data_sha256": digest(data), "value_samples_sha256": digest(ref),
                                   "first_value_sample": ref[0].tolist(), "last_value_sample": ref[-1].tolist(),
