@@ -63,8 +63,8 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //        narrow launches   39 guard on every coefficient
 //     43 k_blind_rotate_w4r: four waves per gate, rows split 2 : 1 : 2 : 1, one hand-over per step -- the default of launches
 //        of one to two gates per CU (4.4 ms against w2r's 5.2)   44 guard on every coefficient
-//     measured and NOT faster (kept as the A/B partners): 40 k_blind_rotate_wide on one limb built for two workgroups per CU
-//     (186 spilled registers), 41 k_blind_rotate_wide4b (the same for wide4: 5.7 ms at 512 gates against w2r's 5.2),
+//     measured and NOT faster (kept as the A/B partners): 41 k_blind_rotate_wide4b (wide4 built for two workgroups per CU:
+//     5.7 ms at 512 gates against w2r's 5.2; the same build of k_blind_rotate_wide spilled 186 registers and was dropped),
 //     42 k_blind_rotate_w1b with the rows software-pipelined (next row's digits under this row's last transpose: -1 %)
 int32_t default_variant();
 constexpr int32_t kVariantWide = 7;

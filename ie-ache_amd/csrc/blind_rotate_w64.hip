@@ -1663,10 +1663,8 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const do
 // LIMBS = 1: the same kernel on the one-limb spectrum [n][2L][2][8][64] -- waves 0 and 1 own the two output polynomials,
 // half the BK bytes and LDS reads per step, guarded rounding (`guard`, see k_blind_rotate_w1).
 // XF / XI: which transposes of the forward / inverse transform go cross-lane instead of through LDS (bit 0 lane-high, bit 1 lane-low)
-// MINW: waves per SIMD the build must allow (3: at most 168 VGPRs, so that TWO workgroups of 2L = 6 waves share a CU --
-// launches of one to two gates per CU)
-template <int L, int BGBIT, bool DIAG, int LIMBS = 2, int XF = 0, int XI = 0, int MINW = 1>
-__global__ __launch_bounds__(128 * L, MINW) void k_blind_rotate_wide(DevKeys K, const double2* __restrict__ bkf,
+template <int L, int BGBIT, bool DIAG, int LIMBS = 2, int XF = 0, int XI = 0>
+__global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const double2* __restrict__ bkf,
                                                              const uint16_t* __restrict__ st_bara, int32_t nb,
                                                              int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
                                                              unsigned long long* diag, const double2* __restrict__ gtw,
@@ -2511,15 +2509,6 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
                            st_acc, i0, i1, e, guard, gtw);
         return;
     }
-    if (sub == 27) {  // round 3 experiment: k_blind_rotate_wide on one limb built for two workgroups per CU (<= 168 VGPRs)
-        const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
-        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_wide<L, BGBIT, false, 1, 0, 0, 3>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_wide<1 limb, 2 per CU>");
-        hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false, 1, 0, 0, 3>), dim3((unsigned)items), dim3(128 * L), lds_wide, stream, K, d_bkf1,
-                           st_bara, nb, st_acc, i0, i1, e, (unsigned long long*)nullptr, gtw, guard);
-        return;
-    }
     if (sub == 25 || sub == 26) {  // round 3: latency kernel with four output waves on half the rows each; 26 = guard on every coefficient
         const size_t lds_w4 = (size_t)((2 * L + 4) * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
         static const bool attr_set =
@@ -2593,7 +2582,7 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
     const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || (variant >= kVariantWideOneLimb && variant <= kVariantWideOneLimb + 7) ||
-                               variant == kVariantOneLimb + 25 || variant == kVariantOneLimb + 26 || variant == kVariantOneLimb + 27 || variant == kVariantOneLimb + 28) ? nb : 64;
+                               variant == kVariantOneLimb + 25 || variant == kVariantOneLimb + 26 || variant == kVariantOneLimb + 28) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
