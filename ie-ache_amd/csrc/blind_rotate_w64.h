@@ -65,7 +65,9 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //        of one to two gates per CU (4.4 ms against w2r's 5.2)   44 guard on every coefficient
 //     measured and NOT faster (kept as the A/B partners): 41 k_blind_rotate_wide4b (wide4 built for two workgroups per CU:
 //     5.7 ms at 512 gates against w2r's 5.2; the same build of k_blind_rotate_wide spilled 186 registers and was dropped),
-//     42 k_blind_rotate_w1b with the rows software-pipelined (next row's digits under this row's last transpose: -1 %)
+//     42 k_blind_rotate_w1b with the rows software-pipelined (next row's digits under this row's last transpose: -1 %),
+//     45 / 46 k_blind_rotate_w1b with both transposes of three / all six forward transforms cross-lane (two-instruction
+//     v_cndmask_b32_dpp exchanges, no LDS round trip: -2 % / -5.5 %)
 int32_t default_variant();
 constexpr int32_t kVariantWide = 7;
 constexpr int32_t kVariantOneLimb = 13;

@@ -186,24 +186,37 @@ __device__ __forceinline__ void swap_dwords(unsigned& lo, unsigned& hi, int lane
 // itself -- new_hi = set ? hi : lo[lane ^ 8], new_lo = set ? hi[lane ^ 8] : lo with set = lane bit 3, VCC flipped in between
 // by the scalar unit -- 2 per pair, into fresh registers.  Four dwords (one double2) per block; the s_nop covers the
 // VALU-write -> DPP-read wait states the assembler does not insert inside an asm block.
-__device__ __forceinline__ void swap4_bit3(unsigned (&a)[4], unsigned (&b)[4]) {
+#define IEACHE_SWAP4_DPP(MASK, CTRL_HI, CTRL_LO, BC)                                                              \
+    asm volatile("s_mov_b32 vcc_lo, " MASK "\n\t"                                                                \
+                 "s_mov_b32 vcc_hi, " MASK "\n\t"                                                                \
+                 "s_nop 1\n\t"                                                                                   \
+                 "v_cndmask_b32_dpp %4, %8, %12, vcc " CTRL_HI " row_mask:0xf bank_mask:0xf" BC "\n\t"                  \
+                 "v_cndmask_b32_dpp %5, %9, %13, vcc " CTRL_HI " row_mask:0xf bank_mask:0xf" BC "\n\t"                  \
+                 "v_cndmask_b32_dpp %6, %10, %14, vcc " CTRL_HI " row_mask:0xf bank_mask:0xf" BC "\n\t"                 \
+                 "v_cndmask_b32_dpp %7, %11, %15, vcc " CTRL_HI " row_mask:0xf bank_mask:0xf" BC "\n\t"                 \
+                 "s_not_b64 vcc, vcc\n\t"                                                                        \
+                 "v_cndmask_b32_dpp %0, %12, %8, vcc " CTRL_LO " row_mask:0xf bank_mask:0xf" BC "\n\t"                  \
+                 "v_cndmask_b32_dpp %1, %13, %9, vcc " CTRL_LO " row_mask:0xf bank_mask:0xf" BC "\n\t"                  \
+                 "v_cndmask_b32_dpp %2, %14, %10, vcc " CTRL_LO " row_mask:0xf bank_mask:0xf" BC "\n\t"                 \
+                 "v_cndmask_b32_dpp %3, %15, %11, vcc " CTRL_LO " row_mask:0xf bank_mask:0xf" BC                    \
+                 : "=&v"(na0), "=&v"(na1), "=&v"(na2), "=&v"(na3), "=&v"(nb0), "=&v"(nb1), "=&v"(nb2), "=&v"(nb3)   \
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3])           \
+                 : "vcc")
+// new_b = set ? b : a[partner], new_a = set ? b[partner] : a, set = lane bit B, partner = lane ^ (1 << B); lanes whose
+// DPP source falls outside the row (bit 2: row_shl / row_shr by 4) take the other operand anyway, but WITHOUT bound_ctrl
+// such a lane is not written at all
+template <int B>
+__device__ __forceinline__ void swap4_dpp(unsigned (&a)[4], unsigned (&b)[4]) {
     unsigned na0, na1, na2, na3, nb0, nb1, nb2, nb3;
-    asm volatile(
-        "s_mov_b32 vcc_lo, 0xff00ff00\n\t"
-        "s_mov_b32 vcc_hi, 0xff00ff00\n\t"
-        "s_nop 1\n\t"
-        "v_cndmask_b32_dpp %4, %8, %12, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %5, %9, %13, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %6, %10, %14, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %7, %11, %15, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_not_b64 vcc, vcc\n\t"
-        "v_cndmask_b32_dpp %0, %12, %8, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %1, %13, %9, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %2, %14, %10, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %3, %15, %11, vcc row_ror:8 row_mask:0xf bank_mask:0xf"
-        : "=&v"(na0), "=&v"(na1), "=&v"(na2), "=&v"(na3), "=&v"(nb0), "=&v"(nb1), "=&v"(nb2), "=&v"(nb3)
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3])
-        : "vcc");
+    if constexpr (B == 3) {
+        IEACHE_SWAP4_DPP("0xff00ff00", "row_ror:8", "row_ror:8", "");
+    } else if constexpr (B == 2) {
+        IEACHE_SWAP4_DPP("0xf0f0f0f0", "row_shl:4", "row_shr:4", " bound_ctrl:0");  // out-of-row sources read 0 and are not selected
+    } else if constexpr (B == 1) {
+        IEACHE_SWAP4_DPP("0xcccccccc", "quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]", "");
+    } else {
+        IEACHE_SWAP4_DPP("0xaaaaaaaa", "quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]", "");
+    }
     a[0] = na0, a[1] = na1, a[2] = na2, a[3] = na3;
     b[0] = nb0, b[1] = nb1, b[2] = nb2, b[3] = nb3;
 }
@@ -219,8 +232,8 @@ __device__ __forceinline__ void bitswap(double2 (&x)[8], int lane) {
                          (unsigned)__double2hiint(x[r].y)};
         unsigned b[4] = {(unsigned)__double2loint(x[r | m].x), (unsigned)__double2hiint(x[r | m].x), (unsigned)__double2loint(x[r | m].y),
                          (unsigned)__double2hiint(x[r | m].y)};
-        if constexpr (B == 3 && SW3 == 1) {
-            swap4_bit3(a, b);
+        if constexpr (B <= 3 && SW3 == 1) {
+            swap4_dpp<B>(a, b);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) swap_dwords<B>(a[q], b[q], lane);
@@ -237,10 +250,11 @@ __device__ __forceinline__ void xlane_hi(double2 (&x)[8], int lane) {
     bitswap<5>(x, lane);
 }
 // register index <-> lane bits 0..2 (what the second LDS transpose does)
+template <int SW3 = 1>
 __device__ __forceinline__ void xlane_lo(double2 (&x)[8], int lane) {
-    bitswap<0>(x, lane);
-    bitswap<1>(x, lane);
-    bitswap<2>(x, lane);
+    bitswap<0, SW3>(x, lane);
+    bitswap<1, SW3>(x, lane);
+    bitswap<2, SW3>(x, lane);
 }
 
 // Transpose tiles hold element (h, m, l) -- three 3-bit digits -- at h*72 + m*9 + l.
@@ -330,7 +344,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
         __builtin_amdgcn_sched_barrier(0);
     }
     if (XLANE & 2) {
-        xlane_lo(x, lane);                                          // reg k1 <-> lane bits 0..2: lane = (k0, k1), reg = p0
+        xlane_lo<SW3>(x, lane);                                     // reg k1 <-> lane bits 0..2: lane = (k0, k1), reg = p0
     } else {
 #pragma unroll
         for (int k1 = 0; k1 < 8; k1++) sT[blk + 9 * k1] = x[k1];    // element (k0, k1, p0), lane = (k0, p0)
@@ -1002,7 +1016,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
         };
         auto digit_row = [&](const int sh, const int brow, auto first, auto via_lds) {
             constexpr bool FIRST = decltype(first)::value;
-            constexpr int XL = decltype(via_lds)::value ? 0 : 1;
+            constexpr int XL = decltype(via_lds)::value == 1 ? 0 : (decltype(via_lds)::value == 2 ? 3 : 1);  // 0: lane-high cross-lane, 1: both through LDS, 2: both cross-lane
             double2 x[8], bA[8], bB[8];
             load_bk_block<true>(bA, bk_rsrc, lane16, brow, bkf1);
 #pragma unroll
@@ -1083,26 +1097,27 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
             }
         } else {
         decompose(pb0);
-        digit_row(32 - BGBIT, bki, std::true_type{}, std::false_type{});
+        digit_row(32 - BGBIT, bki, std::true_type{}, std::integral_constant<int, (XMIX >= 4 ? 2 : 0)>{});
         if (XMIX == 2) {
 #pragma unroll 1
             for (int row = 1; row < 2 * L; row += 2) {   // odd rows through LDS, even rows cross-lane
                 if (row == L) decompose(pb0 + 4096u);
                 const int q = row >= L ? row - L : row;
-                digit_row(32 - (q + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::true_type{});
+                digit_row(32 - (q + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::integral_constant<int, 1>{});
                 if (row + 1 < 2 * L) {
                     if (row + 1 == L) decompose(pb0 + 4096u);
                     const int q2 = row + 1 >= L ? row + 1 - L : row + 1;
-                    digit_row(32 - (q2 + 1) * BGBIT, bki + (row + 1) * kRowBytes, std::false_type{}, std::false_type{});
+                    digit_row(32 - (q2 + 1) * BGBIT, bki + (row + 1) * kRowBytes, std::false_type{}, std::integral_constant<int, 0>{});
                 }
             }
         } else {
 #pragma unroll 1
-            for (int row = 1; row < L; row++) digit_row(32 - (row + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::false_type{});
+            for (int row = 1; row < L; row++)
+                digit_row(32 - (row + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::integral_constant<int, (XMIX >= 4 ? 2 : 0)>{});
             decompose(pb0 + 4096u);
 #pragma unroll 1
             for (int row = L; row < 2 * L; row++)
-                digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::integral_constant<bool, XMIX == 1>{});
+                digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::integral_constant<int, (XMIX == 1 ? 1 : XMIX == 5 ? 2 : 0)>{});
         }
         }
         fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
@@ -2536,6 +2551,8 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         case 20: IEACHE_W1B(2, 1) return;   // polynomial 1's forward transposes through LDS
         case 21: IEACHE_W1B(2, 2) return;   // every second row's
         case 22: IEACHE_W1B(0, 0) return;   // no guard arithmetic (measurement)
+        case 32: IEACHE_W1B(2, 4) return;   // polynomial 0's forward transforms with BOTH transposes cross-lane (no LDS round trip), polynomial 1's lane-low through LDS
+        case 33: IEACHE_W1B(2, 5) return;   // all six
         case 29: IEACHE_W1B(2, 3) return;   // rows software-pipelined: the next row's digits / twist under this row's last transpose
         default: break;
     }
