@@ -34,6 +34,7 @@ for it in range(passes):
     total += st.bootstraps
     dev, reruns = ctx.fft_guard()
     print("pass %d %s: %d bootstraps in %.1f s, all %d products correct: %s; so far %.3g rounded coefficients, "
-          "largest distance to an integer %.6f (limit 0.0625, wrong bit at 0.5), calls repeated on the two-limb kernels: %d"
+          "largest distance to an integer among the watched quarter %.6f (limit 0.0625, wrong bit at 0.5), calls repeated on the "
+          "two-limb kernels: %d; audit %s"
           % (it, "carry-save" if kind == ia.CIRC_MUL_WALLACE else "cloud.c mul32", st.bootstraps, time.time() - t0, batch, ok,
-             total * 630.0 * 2048, dev, reruns), flush=True)
+             total * 630.0 * 2048, dev, reruns, ctx.fft_audit()), flush=True)
