@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <tuple>
 
 #include <sys/time.h>
@@ -81,18 +82,54 @@ CloudDirSession::~CloudDirSession() {
 int cloud_run(const std::string& dir, Evaluator* shared_eval, CloudRunReport* report, int device, FILE* log) {
     if (!log) log = stdout;
     const std::string d = dir.empty() ? std::string(".") : dir;
+    // IEACHE_TIMING=1: where a cold ./cloud spends its time (stderr), phase by phase
+    static const bool timing = getenv("IEACHE_TIMING") && atoi(getenv("IEACHE_TIMING")) != 0;
+    double t_last = now_s();
+    auto tick = [&](const char* what) {
+        if (!timing) return;
+        const double t = now_s();
+        fprintf(stderr, "[cloud-timing] %-44s %8.1f ms\n", what, (t - t_last) * 1e3);
+        t_last = t;
+    };
     fprintf(log, "Reading the key...\n");
     // cloud.c:656-663
     CloudKeyData ck;
     std::unique_ptr<Evaluator> owned;
-    if (!shared_eval) load_cloud_key(d + "/cloud.key", &ck);
+    // A cold process (the reference starts ./cloud once per operator) spends ~150 ms bringing up the HIP runtime and
+    // ~45 ms reading and decoding the 114 MB key file: do the two at the same time.
+    std::thread warm;
+    if (!shared_eval) {
+        warm = std::thread([device] {
+            if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);  // forces runtime + context creation; errors resurface in Evaluator()
+        });
+        try {
+            load_cloud_key(d + "/cloud.key", &ck);
+        } catch (...) {
+            warm.join();
+            throw;
+        }
+    }
+    struct Joiner {
+        std::thread& t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{warm};
+    tick("cloud.key read and decoded");
     CloudDirSession session(d, shared_eval ? shared_eval->params() : ck.p, log);
-    return cloud_run_io(session.io, [&]() -> Evaluator* {
+    tick("nbit.key, cloud.data, operator.txt opened");
+    const int rc = cloud_run_io(session.io, [&]() -> Evaluator* {
         if (shared_eval) return shared_eval;
+        tick("inputs read, metadata words written");
+        if (warm.joinable()) warm.join();
         owned.reset(new Evaluator(ck.p, device));
+        tick("HIP runtime + evaluator created");
         owned->load_keys_host(ck.bk.data(), ck.ksk.data());
+        tick("key uploaded, spectra / limb matrix built");
         return owned.get();
     }, report);
+    tick("circuit evaluated, answer.data written");
+    return rc;
 }
 
 // Everything main() does before its circuit: inputs, metadata arithmetic in the clear, the 64 metadata samples of
