@@ -67,7 +67,8 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //     5.7 ms at 512 gates against w2r's 5.2; the same build of k_blind_rotate_wide spilled 186 registers and was dropped),
 //     42 k_blind_rotate_w1b with the rows software-pipelined (next row's digits under this row's last transpose: -1 %),
 //     45 / 46 k_blind_rotate_w1b with both transposes of three / all six forward transforms cross-lane (two-instruction
-//     v_cndmask_b32_dpp exchanges, no LDS round trip: -2 % / -5.5 %)
+//     v_cndmask_b32_dpp exchanges, no LDS round trip: -2 % / -5.5 %), 47 / 48 k_blind_rotate_w1b taking the first / both twiddle
+//     sets from the global table through the buffer path instead of LDS (105 of 341 LDS instructions per step: -2 % / -4 %)
 int32_t default_variant();
 constexpr int32_t kVariantWide = 7;
 constexpr int32_t kVariantOneLimb = 13;

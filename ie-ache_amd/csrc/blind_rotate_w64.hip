@@ -110,6 +110,27 @@ constexpr int kTwElems = 8 * 64 + 8 * 8;
 struct LaneRoots {
     const double2* t1;  // &tw[lane], stride 64
     const double2* t2;  // &tw[512 + (lane & 7)], stride 8
+    __device__ __forceinline__ double2 a(int k) const { return t1[k * 64]; }
+    __device__ __forceinline__ double2 b(int k) const { return t2[k * 8]; }
+};
+// The same table read from GLOBAL memory through the buffer path (SGPR resource, one per-lane byte offset, the index as the
+// instruction's immediate): twiddle reads leave the LDS pipe for the vector-memory one.  FROM: 1 = only the first set
+// (a, 8 per transform), 2 = both; the rest comes from the LDS copy.
+typedef int v4i_tw __attribute__((ext_vector_type(4)));
+template <int FROM>
+struct BufRoots {
+    LaneRoots lds;
+    __amdgpu_buffer_rsrc_t rsrc;
+    int off1, off2;  // byte offsets of tw[lane] and tw[512 + (lane & 7)]
+    __device__ __forceinline__ double2 a(int k) const {
+        const v4i_tw d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off1, k * 1024, 0);
+        return make_double2(__hiloint2double(d.y, d.x), __hiloint2double(d.w, d.z));
+    }
+    __device__ __forceinline__ double2 b(int k) const {
+        if (FROM < 2) return lds.b(k);
+        const v4i_tw d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off2, k * 128, 0);
+        return make_double2(__hiloint2double(d.y, d.x), __hiloint2double(d.w, d.z));
+    }
 };
 
 __device__ __forceinline__ void build_twiddles(double2* tw, int tid, int nthreads) {
@@ -275,15 +296,15 @@ struct NoHook {
 // request data the caller needs right after the transform
 // POST: called once the reads of the last (lane-low) transpose are issued and before their data is used: work that does not
 // depend on them runs under that LDS round trip
-template <bool WSYNC, int XLANE = 0, int ILV = 0, class MID = NoHook, bool MID_LATE = false, int SW3 = 1, class POST = NoHook>
-__device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R, MID mid = MID(), POST post = POST()) {
+template <bool WSYNC, int XLANE = 0, int ILV = 0, class MID = NoHook, bool MID_LATE = false, int SW3 = 1, class POST = NoHook, class ROOTS = LaneRoots>
+__device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const ROOTS& R, MID mid = MID(), POST post = POST()) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
     const int blk = hi * 72 + lo;  // (h, l) = (lane>>3, lane&7)
     // twiddles are fetched from the LDS table ahead of the butterflies that hide their latency
     double2 tA[8], tB[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
+    for (int k = 0; k < 8; k++) tA[k] = R.a(k);
     dft8<false>(x);                          // over r -> k0
     if (ILV && !(XLANE & 1)) {
         __builtin_amdgcn_sched_barrier(0);
@@ -294,7 +315,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
+        for (int k = 1; k < 8; k++) tB[k] = R.b(k);
         tile_sync<WSYNC>();
 #pragma unroll
         for (int p1 = 0; p1 < 8; p1++) x[p1] = sT[blk + 9 * p1];
@@ -324,7 +345,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
+    for (int k = 1; k < 8; k++) tB[k] = R.b(k);
     if (XLANE & 1) {
         xlane_hi<SW3>(x, lane);                                     // reg k0 <-> lane bits 3..5: lane = (k0, p0), reg = p1
     } else {
@@ -365,16 +386,16 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
 // Inverse of fft512_forward (unnormalised: 512 x), also removing the lane part of the twist:
 //   in : spectrum in the layout fft512_forward produces
 //   out: x[r] = y_{64r+lane} * exp(i*pi*r/16)   (caller multiplies by exp(-i*pi*r/16))
-template <bool WSYNC, int XLANE = 0>
-__device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
+template <bool WSYNC, int XLANE = 0, class ROOTS = LaneRoots>
+__device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int lane, const ROOTS& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo, blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
     double2 tA[8], tB[8];
 #pragma unroll
-    for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
+    for (int k = 1; k < 8; k++) tB[k] = R.b(k);
     dft8<true>(x);  // k2 -> p0 ; lane = (k0, k1)
 #pragma unroll
-    for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
+    for (int k = 0; k < 8; k++) tA[k] = R.a(k);
     if (XLANE & 2) {
         xlane_lo(x, lane);                                          // back to lane = (k0, p0), reg = k1
     } else {
@@ -408,14 +429,14 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int
 // long as each [write, read] pair of one transform is issued whole, the other transform's
 // butterflies run while that round trip is in flight.  (Alone, a wave spends ~2/3 of a
 // transform waiting on its four LDS round trips.)
-template <bool WSYNC>
+template <bool WSYNC, class ROOTS = LaneRoots>
 __device__ __forceinline__ void fft512_inverse_pair(double2 (&x)[8], double2 (&y)[8], double2* sT, int lane,
-                                                    const LaneRoots& R) {
+                                                    const ROOTS& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo, blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
     double2 tA[8], tB[8];
 #pragma unroll
-    for (int k = 1; k < 8; k++) tB[k] = R.t2[k * 8];
+    for (int k = 1; k < 8; k++) tB[k] = R.b(k);
     dft8<true>(x);
 #pragma unroll
     for (int q = 0; q < 8; q++) sT[rd + q] = x[q];
@@ -425,7 +446,7 @@ __device__ __forceinline__ void fft512_inverse_pair(double2 (&x)[8], double2 (&y
     dft8<true>(y);                                                // ... under y's first pass
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 8; k++) tA[k] = R.t1[k * 64];
+    for (int k = 0; k < 8; k++) tA[k] = R.a(k);
 #pragma unroll
     for (int q = 0; q < 8; q++) sT[rd + q] = y[q];               // issued after x's reads: in-order LDS keeps them apart
     tile_sync<WSYNC>();
@@ -948,7 +969,9 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
 //   * XMIX: which forward transforms take their lane-high transpose through LDS instead of cross-lane
 //     (0 none, 1 the rows of polynomial 1, 2 every second row): balances vector issue against LDS stores.
 // dynamic LDS: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2          (78 848 B -> 2 per CU)
-template <int L, int BGBIT, int GUARD, int XMIX = 0>
+// TWG: where the transforms take their twiddles from: 0 the LDS copy, 1 the first inter-pass set (8 per transform) from the
+// global table (L1 / L2), 2 both sets -- 105 of a step's 341 LDS instructions moved to the vector-memory path
+template <int L, int BGBIT, int GUARD, int XMIX = 0, int TWG = 0>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K, const double2* __restrict__ bkf1,
                                                                        const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                        int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -966,7 +989,14 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
     load_twiddles(sTw, gtw, tid, 64 * kW1Gates);
     __syncthreads();  // the only workgroup barrier
     if (item >= items) return;
-    const LaneRoots R = make_roots(sTw, lane);
+    const LaneRoots Rl = make_roots(sTw, lane);
+    const BufRoots<(TWG ? TWG : 1)> Rb{Rl, __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(gtw), (short)0, kTwElems * (int)sizeof(double2), 0x00020000),
+                                       lane * (int)sizeof(double2), (512 + (lane & 7)) * (int)sizeof(double2)};
+    auto roots = [&]() -> decltype(auto) {
+        if constexpr (TWG == 0) return (Rl);
+        else return (Rb);
+    };
+    const auto& R = roots();
     const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
     int32_t* gacc = st_acc + (size_t)item * 2 * kN;
     {
@@ -1027,7 +1057,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
                               : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
             __builtin_amdgcn_sched_barrier(0);
-            fft512_forward<true, XL, 0>(x, sT, lane, R);
+            fft512_forward<true, XL, 0, NoHook, false, 1, NoHook>(x, sT, lane, R);
             load_bk_block<true>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2553,6 +2583,8 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         case 22: IEACHE_W1B(0, 0) return;   // no guard arithmetic (measurement)
         case 32: IEACHE_W1B(2, 4) return;   // polynomial 0's forward transforms with BOTH transposes cross-lane (no LDS round trip), polynomial 1's lane-low through LDS
         case 33: IEACHE_W1B(2, 5) return;   // all six
+        case 34: IEACHE_W1B(2, 0, 1) return;   // first inter-pass twiddles from the global table instead of LDS
+        case 35: IEACHE_W1B(2, 0, 2) return;   // both sets
         case 29: IEACHE_W1B(2, 3) return;   // rows software-pipelined: the next row's digits / twist under this row's last transpose
         default: break;
     }
