@@ -68,7 +68,9 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //     42 k_blind_rotate_w1b with the rows software-pipelined (next row's digits under this row's last transpose: -1 %),
 //     45 / 46 k_blind_rotate_w1b with both transposes of three / all six forward transforms cross-lane (two-instruction
 //     v_cndmask_b32_dpp exchanges, no LDS round trip: -2 % / -5.5 %), 47 / 48 k_blind_rotate_w1b taking the first / both twiddle
-//     sets from the global table through the buffer path instead of LDS (105 of 341 LDS instructions per step: -2 % / -4 %)
+//     sets from the global table through the buffer path instead of LDS (105 of 341 LDS instructions per step: -2 % / -4 %),
+//     50 k_blind_rotate_w1b with every wave touching one 8 KiB slice of the NEXT step's BK blocks per step (L2 prefetch: -1.3 %)
+//     49 k_blind_rotate_w1b with s_memtime phase stamps on stderr (diagnostic)
 int32_t default_variant();
 constexpr int32_t kVariantWide = 7;
 constexpr int32_t kVariantOneLimb = 13;

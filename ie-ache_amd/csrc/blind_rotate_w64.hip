@@ -971,12 +971,17 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
 // dynamic LDS: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2          (78 848 B -> 2 per CU)
 // TWG: where the transforms take their twiddles from: 0 the LDS copy, 1 the first inter-pass set (8 per transform) from the
 // global table (L1 / L2), 2 both sets -- 105 of a step's 341 LDS instructions moved to the vector-memory path
-template <int L, int BGBIT, int GUARD, int XMIX = 0, int TWG = 0>
+// PF: L2 prefetch of the NEXT step's BK blocks.  All resident waves of an XCD walk the same BK blocks nearly in step, so the
+// first wave to touch a block takes the L2 miss (Infinity Cache, ~2 k cycles) and the others queue behind the same fill:
+// phase stamps (br_variant 49) put ~1.8 k cycles of waiting into every digit row.  With PF every wave, once per step, touches
+// one 8 KiB slice of BK_{i+1} -- one buffer_load_dword, each lane a different 128-byte line, the slice picked by the wave's
+// number so that the waves of an XCD cover all twelve many times over -- a whole step before anybody needs it.
+template <int L, int BGBIT, int GUARD, int XMIX = 0, int TWG = 0, bool DIAG = false, bool PF = false>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K, const double2* __restrict__ bkf1,
                                                                        const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                        int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
                                                                        Torus32* ext, unsigned* guard,
-                                                                       const double2* __restrict__ gtw) {
+                                                                       const double2* __restrict__ gtw, unsigned long long* diag = nullptr) {
     extern __shared__ __align__(16) unsigned char smem[];
     int32_t* acc_all = reinterpret_cast<int32_t*>(smem);
     double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)kW1Gates * 2 * kN * 4);
@@ -1020,6 +1025,17 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
     const unsigned char* accb = reinterpret_cast<const unsigned char*>(acc_all);  // LDS offset 0 of the workgroup
     const uint32_t pb0 = (uint32_t)wave * (2 * kN * 4);                            // this gate's polynomial 0; polynomial 1 at + 4096
 
+    constexpr int kPfSlices = kStepBytes / (64 * 128);  // 128-byte lines of a step's BK blocks, 64 per wave-instruction
+    const int pf_off = (int)((((blockIdx.x >> 3) * kW1Gates + wave) % kPfSlices) * 64 + lane) * 128;
+    int pf_sink = 0;
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    if (DIAG) tlast = stamp();
+#define IEACHE_STAMP(idx)                      \
+    if (DIAG) {                                \
+        const unsigned long long t_ = stamp(); \
+        tsum[idx] += t_ - tlast;               \
+        tlast = t_;                            \
+    }
     const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
 #pragma unroll 1
     for (int32_t i = i0; i < i1; i++) {
@@ -1057,7 +1073,9 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
                               : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
             __builtin_amdgcn_sched_barrier(0);
+            IEACHE_STAMP(1)
             fft512_forward<true, XL, 0, NoHook, false, 1, NoHook>(x, sT, lane, R);
+            IEACHE_STAMP(2)
             load_bk_block<true>(bB, bk_rsrc, lane16, brow + kRowBytes / 2, bkf1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1070,6 +1088,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
                 s[1][k] = FIRST ? cmulx<false>(x[k], bB[k])
                                 : make_double2(fma(x[k].x, bB[k].x, fma(-x[k].y, bB[k].y, s[1][k].x)),
                                                fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
+            IEACHE_STAMP(3)
         };
         if (XMIX == 3) {
             // software pipeline over the 2L rows: the digits / conversion / twist of row + 1 (and, before the first row of
@@ -1127,6 +1146,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
             }
         } else {
         decompose(pb0);
+        IEACHE_STAMP(0)
         digit_row(32 - BGBIT, bki, std::true_type{}, std::integral_constant<int, (XMIX >= 4 ? 2 : 0)>{});
         if (XMIX == 2) {
 #pragma unroll 1
@@ -1145,12 +1165,18 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
             for (int row = 1; row < L; row++)
                 digit_row(32 - (row + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::integral_constant<int, (XMIX >= 4 ? 2 : 0)>{});
             decompose(pb0 + 4096u);
+            IEACHE_STAMP(0)
 #pragma unroll 1
             for (int row = L; row < 2 * L; row++)
                 digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{}, std::integral_constant<int, (XMIX == 1 ? 1 : XMIX == 5 ? 2 : 0)>{});
         }
         }
+        if (PF) {  // nothing reads the result; its slot in the in-order return queue is long gone when the next step's loads wait
+            pf_sink = __builtin_amdgcn_raw_buffer_load_b32(bk_rsrc, pf_off, bki + kStepBytes, 0);
+            asm volatile("" ::"v"(pf_sink));
+        }
         fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
+        IEACHE_STAMP(4)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             uint32_t* accc = reinterpret_cast<uint32_t*>(acc) + c * kN;
@@ -1181,6 +1207,12 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
             }
         }
         wave_sync();
+        IEACHE_STAMP(5)
+    }
+#undef IEACHE_STAMP
+    if (DIAG && diag && lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) atomicAdd(&diag[(wave & 1) * 8 + t], tsum[t]);
     }
     if (GUARD) {
         float m = (float)dev_max;
@@ -2583,6 +2615,15 @@ static void launch_slice_w1(int sub, int64_t items, hipStream_t stream, const De
         case 22: IEACHE_W1B(0, 0) return;   // no guard arithmetic (measurement)
         case 32: IEACHE_W1B(2, 4) return;   // polynomial 0's forward transforms with BOTH transposes cross-lane (no LDS round trip), polynomial 1's lane-low through LDS
         case 33: IEACHE_W1B(2, 5) return;   // all six
+        case 36: {  // phase stamps (diagnostic): decomposition / digits+twist / forward transform / BK + products / inverse pair / update
+            static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_w1b<L, BGBIT, 2, 0, 0, true>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_w1()) == hipSuccess;
+            if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_w1b<diag>");
+            hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, 2, 0, 0, true>), grid, blk, lds_bytes_w1(), stream, K, d_bkf1, st_bara, nb, st_acc, items, i0, i1,
+                               e, guard, gtw, diag_buf());
+            return;
+        }
+        case 37: IEACHE_W1B(2, 0, 0, false, true) return;   // L2 prefetch of the next step's BK blocks, one slice per wave
         case 34: IEACHE_W1B(2, 0, 1) return;   // first inter-pass twiddles from the global table instead of LDS
         case 35: IEACHE_W1B(2, 0, 2) return;   // both sets
         case 29: IEACHE_W1B(2, 3) return;   // rows software-pipelined: the next row's digits / twist under this row's last transpose
@@ -2646,6 +2687,21 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
             launch_slice<3, 7>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, d_twiddles);
         else
             launch_slice<2, 10>(variant, grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, d_twiddles);
+    }
+    if (variant == kVariantOneLimb + 36) {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, diag_buf(), sizeof h, hipMemcpyDeviceToHost);
+        (void)hipMemset(diag_buf(), 0, sizeof h);
+        static const char* names[6] = {"decomposition (x2)", "digits+cvt+twist (x6)", "forward transform (x6)", "2nd BK block + products (x6)", "inverse pair", "round+update"};
+        const double denom = (double)items * (nsteps > 0 ? nsteps : 1) / 2.0;  // each of the two slots collects half of the waves
+        for (int w = 0; w < 2; w++) {
+            double tot = 0;
+            for (int t = 0; t < 6; t++) tot += (double)h[w * 8 + t];
+            fprintf(stderr, "[br-diag w1b] waves %d mod 2: %.0f memtime ticks per step:", w, tot / denom);
+            for (int t = 0; t < 6; t++) fprintf(stderr, " %s=%.0f", names[t], (double)h[w * 8 + t] / denom);
+            fprintf(stderr, "\n");
+        }
     }
     if (variant == 1 || variant == 4 || variant == kVariantWide + 1 || variant == kVariantWideOneLimb + 7) diag_report(stream, items, nsteps, variant == kVariantWideOneLimb + 7 ? kVariantWide + 1 : variant);
     if (nsteps == 0 && ext) {

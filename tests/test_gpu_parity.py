@@ -728,7 +728,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     # (transposes through LDS / cross-lane); round 3: 31-35 and 42 k_blind_rotate_w1b (31 = the default of wide launches, 42 its
     # software-pipelined rows), 36 / 37 k_blind_rotate_w2r (mid-size default), 38 / 39 k_blind_rotate_wide4 (narrow default),
     # 41 the latency kernel built for two workgroups per CU, 43 / 44 k_blind_rotate_w4r (one to two gates per CU)
-    for variant in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 41, 42, 43, 44, 45, 46, 47, 48):
+    for variant in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 41, 42, 43, 44, 45, 46, 47, 48, 50):
         ctx.set_option("br_variant", variant)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), variant
     for variant in (13, 31):
