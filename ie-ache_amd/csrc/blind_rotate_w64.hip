@@ -1,25 +1,24 @@
-// Blind rotation for the N=1024 ring, two 64-lane wavefronts per gate.
+// Blind rotation for the N=1024 ring (tfhe_blindRotate_FFT of libtfhe), on 64-lane wavefronts.
 //
-// Same mathematics as k_blind_rotate_generic (tfhe_blindRotate_FFT of libtfhe,
-// SURVEY.md App. A steps 2-5) with the exact two-limb FP64 negacyclic transform,
-// re-laid out for CDNA4:
-//   * the 512-point complex transform is 8 x 8 x 8: three radix-8 passes done
-//     entirely in registers (8 points per lane), separated by two register<->lane
-//     transposes -- through a padded, bank-conflict-free LDS tile per wave (default)
-//     or cross-lane with v_permlane*_swap / DPP (selectable variants);
-//   * the spectrum stays in registers between the forward transform, the
-//     point-wise multiply-accumulate with BK_i and the inverse transform; BK_i
-//     is stored in exactly the (register, lane) order the forward transform
-//     leaves its output in, so every BK load is one coalesced 1 KiB
-//     global_load_dwordx4 per wave, issued a batch ahead of its MACs;
-//   * wave w of a gate's workgroup decomposes accumulator polynomial w and owns
-//     output polynomial w's two limb sums (the 256 architectural VGPRs do not
-//     hold all four next to a transform); spectra cross waves through LDS;
-//   * the CMux step index is the OUTER loop of the evaluator: one launch
-//     advances every gate of a chunk by a slice of steps, so all resident
-//     workgroups read the same BK blocks while they are hot in the XCD's L2;
-//   * the accumulator (2 x 1024 int32) lives in LDS only because the X^a
-//     rotation needs arbitrary shifts; twiddles come from a 9 KiB LDS table.
+// Same mathematics as k_blind_rotate_generic, re-laid out for CDNA4:
+//   * the 512-point complex transform is 8 x 8 x 8: three radix-8 passes done entirely in registers (8 points per lane),
+//     separated by two register<->lane transposes -- through a padded, bank-conflict-free LDS tile per wave, or cross-lane
+//     with v_permlane*_swap / v_cndmask_b32_dpp (the forward lane-high one, by default);
+//   * the spectrum stays in registers between the forward transform, the point-wise multiply-accumulate with BK_i and the
+//     inverse transform; BK_i is stored in exactly the (register, lane) order the forward transform leaves its output in, so
+//     every BK load is one coalesced 1 KiB load per wave, issued ahead of its MACs;
+//   * the CMux step index is the OUTER loop of the evaluator: one launch advances every gate of a chunk by a slice of steps,
+//     so all resident workgroups read the same BK blocks while they are hot in the XCD's L2;
+//   * the accumulator (2 x 1024 int32) lives in LDS only because the X^a rotation needs arbitrary shifts; twiddles come from a
+//     9 KiB LDS table.
+// One kernel per launch-size regime (variant table in blind_rotate_w64.h):
+//   k_blind_rotate_w1b    one wave per gate            launches of more than 5 gates per CU (the throughput kernel)
+//   k_blind_rotate_w2r    two waves per gate           2 .. 5 gates per CU
+//   k_blind_rotate_w4r    four waves per gate          1 .. 2 gates per CU
+//   k_blind_rotate_wide4  2L = 6 waves per gate        at most one gate per CU (single expressions: the reference's own mode)
+// all on the ONE-limb spectrum (libtfhe's own product, rounded to the exact integer under a rounding guard and a sampled
+// audit), and k_blind_rotate_w2 / k_blind_rotate_wide<..., 2> on the TWO-limb spectrum (exact by construction: "exact_fft",
+// repeats, audits).  Earlier kernels and measured dead ends stay selectable as A/B partners.
 #include "blind_rotate_w64.h"
 
 #include <cstdio>
