@@ -104,3 +104,96 @@ class ToyKeys:
     def decrypt_word(self, samples):
         bits = self.decrypt_bits(samples)
         return sum(int(b) << i for i, b in enumerate(bits))
+
+
+# ---- an independent restatement of the gate bootstrap itself (written from the spec alone) ----
+# numpy int64 / Python integers throughout, exact negacyclic products by np.convolve; shares no code with oracle/ or the
+# product.  Slow (toy rings only): it exists so that the C oracle's BITS -- not just its decryptions -- have a second witness.
+
+def _u32(x):
+    return np.asarray(x, dtype=np.int64) & 0xFFFFFFFF
+
+
+def _negacyclic(small, big):
+    """small (int64, |.| < 2^8) * big (int32 torus) mod X^N+1 -> int32 with wraparound."""
+    N = small.shape[0]
+    full = np.convolve(small.astype(object), big.astype(np.int64).astype(object))  # Python integers: no overflow
+    res = [int(full[i]) - (int(full[i + N]) if i + N < len(full) else 0) for i in range(N)]
+    return _wrap32(np.array([r & 0xFFFFFFFF for r in res], dtype=np.int64))
+
+
+def _mul_by_xai(p, a):
+    """X^a * p mod X^N+1 for a in [0, 2N)."""
+    N = p.shape[0]
+    p = p.astype(np.int64)
+    out = np.zeros(N, dtype=np.int64)
+    if a < N:
+        out[:a] = -p[N - a:] if a else out[:0]
+        out[a:] = p[:N - a]
+    else:
+        aa = a - N
+        out[:aa] = p[N - aa:] if aa else out[:0]
+        out[aa:] = -p[:N - aa]
+    return _wrap32(out)
+
+
+def np_modswitch(phase, log2_2N):
+    return int(((int(phase) & 0xFFFFFFFF) + (1 << (31 - log2_2N))) & 0xFFFFFFFF) >> (32 - log2_2N)
+
+
+def np_bootstrap(K, x):
+    """tfhe_bootstrap_FFT(MU) of the LWE sample x under the ToyKeys-style material K (exact arithmetic) -> LWE sample."""
+    n, N, l, Bgbit = K.n, K.N, K.l, K.Bgbit
+    log2_2N = (2 * N).bit_length() - 1
+    barb = np_modswitch(x[n], log2_2N)
+    bara = [np_modswitch(x[i], log2_2N) for i in range(n)]
+    acc = [np.zeros(N, dtype=np.int32), _mul_by_xai(np.full(N, MU, dtype=np.int32), (2 * N - barb) % (2 * N))]
+    Bg, half = 1 << Bgbit, 1 << (Bgbit - 1)
+    offset = sum(half << (32 - p * Bgbit) for p in range(1, l + 1)) & 0xFFFFFFFF
+    for i in range(n):
+        if bara[i] == 0:
+            continue
+        tmp = [_wrap32(_mul_by_xai(acc[u], bara[i]).astype(np.int64) - acc[u].astype(np.int64)) for u in range(2)]
+        rows = []
+        for u in range(2):
+            w = (_u32(tmp[u]) + offset) & 0xFFFFFFFF
+            for p in range(1, l + 1):
+                rows.append(((w >> (32 - p * Bgbit)) & (Bg - 1)) - half)
+        prod = [np.zeros(N, dtype=np.int64), np.zeros(N, dtype=np.int64)]
+        for row, dec in enumerate(rows):
+            for c in range(2):
+                prod[c] += _negacyclic(dec.astype(np.int64), K.bk[i, row, c]).astype(np.int64)
+        acc = [_wrap32(acc[c].astype(np.int64) + prod[c]) for c in range(2)]
+    u = np.zeros(N + 1, dtype=np.int32)
+    u[0] = acc[0][0]
+    u[1:N] = _wrap32(-acc[0][N - 1:0:-1].astype(np.int64))
+    u[N] = acc[1][0]
+    # lweKeySwitch
+    t, basebit = K.ks_t, K.ks_basebit
+    base, prec = 1 << basebit, 1 << (32 - (1 + basebit * t))
+    r = np.zeros(n + 1, dtype=np.int64)
+    r[n] = int(u[N])
+    for i in range(N):
+        abar = (int(u[i]) + prec) & 0xFFFFFFFF
+        for j in range(t):
+            d = (abar >> (32 - (j + 1) * basebit)) & (base - 1)
+            if d:
+                r -= K.ksk[i, j, d].astype(np.int64)
+    return _wrap32(r)
+
+
+def np_gate(K, name, ca, cb):
+    ca, cb = ca.astype(np.int64), cb.astype(np.int64)
+    if name == "and":
+        t = ca + cb
+        t[K.n] -= 1 << 29
+    elif name == "xor":
+        t = 2 * (ca + cb)
+        t[K.n] += 1 << 30
+    elif name == "or":
+        t = ca + cb
+        t[K.n] += 1 << 29
+    else:  # nand
+        t = -ca - cb
+        t[K.n] += 1 << 29
+    return np_bootstrap(K, _wrap32(t))

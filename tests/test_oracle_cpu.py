@@ -66,6 +66,25 @@ def test_gate_truth_tables_numpy_keys(O, toy):
     assert np.array_equal(ck.constant(0), np.r_[np.zeros(K.n, np.int32), np.int32(-MU)])
 
 
+def test_bootstrap_bits_equal_an_independent_numpy_restatement(O):
+    """The C oracle's gate bootstrap against tests/np_tfhe.py's np_bootstrap -- the same spec (mod-switch,
+    test-vector rotation, n CMux steps with the gadget decomposition and exact negacyclic products, sample extraction,
+    key switch) written independently in numpy / Python integers: every coefficient of every output sample identical,
+    for all four gate types and all input combinations, on two toy rings."""
+    import np_tfhe
+    for (n, N, seed) in ((8, 64, 11), (5, 128, 12)):
+        K = np_tfhe.ToyKeys(n=n, N=N, seed=seed)
+        ck = O.CloudKey(K.n, K.N, K.k, K.l, K.Bgbit, K.ks_t, K.ks_basebit, K.bk, K.ksk)
+        a = K.encrypt_bits([0, 0, 1, 1])
+        b = K.encrypt_bits([0, 1, 0, 1])
+        for name, f in (("and", lambda x, y: x & y), ("xor", lambda x, y: x ^ y), ("or", lambda x, y: x | y), ("nand", lambda x, y: 1 - (x & y))):
+            for i in range(4):
+                ref = np_tfhe.np_gate(K, name, a[i], b[i])
+                out = ck.gate(name, a[i], b[i])
+                assert np.array_equal(ref, out), (n, N, name, i)
+                assert K.decrypt_bits(out) == f(i >> 1, i & 1)
+
+
 def test_schoolbook_and_ntt_bootstrap_identical(O, toy):
     K, ck = toy
     x = K.encrypt_bits(1)
