@@ -197,3 +197,18 @@ def np_gate(K, name, ca, cb):
         t = -ca - cb
         t[K.n] += 1 << 29
     return np_bootstrap(K, _wrap32(t))
+
+
+def np_add(K, x, y, c, nb_bits):
+    """Cloud/cloud.c:18-51 `add`, gate by gate on np_gate: per bit axc = x ^ carry, bxc = y ^ carry, sum = x ^ bxc,
+    axc = axc & bxc, carry = carry ^ axc; the final carry is returned beside the sum.  (A second reading of those lines,
+    independent of oracle/cloud_oracle.c.)"""
+    carry = c.copy()
+    out = np.zeros((nb_bits, K.n + 1), dtype=np.int32)
+    for i in range(nb_bits):
+        axc = np_gate(K, "xor", x[i], carry)
+        bxc = np_gate(K, "xor", y[i], carry)
+        out[i] = np_gate(K, "xor", x[i], bxc)
+        axc = np_gate(K, "and", axc, bxc)
+        carry = np_gate(K, "xor", carry, axc)
+    return out, carry

@@ -85,6 +85,22 @@ def test_bootstrap_bits_equal_an_independent_numpy_restatement(O):
                 assert K.decrypt_bits(out) == f(i >> 1, i & 1)
 
 
+def test_add_circuit_bits_equal_the_independent_restatement(O):
+    """orc_add (oracle/cloud_oracle.c) against np_add, a second reading of Cloud/cloud.c:18-51 on top of the independent
+    numpy bootstrap: all sum samples and the carry-out identical, and they decrypt to the integer sum."""
+    import np_tfhe
+    K = np_tfhe.ToyKeys(n=6, N=64, seed=21)
+    ck = O.CloudKey(K.n, K.N, K.k, K.l, K.Bgbit, K.ks_t, K.ks_basebit, K.bk, K.ksk)
+    for (xv, yv, cv) in ((0b1011, 0b0110, 1), (0b1111, 0b1111, 0), (0, 0, 0)):
+        x, y = K.encrypt_word(xv, 4), K.encrypt_word(yv, 4)
+        c = K.encrypt_bits([cv])
+        ref_sum, ref_carry = np_tfhe.np_add(K, x, y, c[0], 4)
+        s, co = ck.add(x, y, c, 4)
+        assert np.array_equal(ref_sum, s) and np.array_equal(ref_carry, co.reshape(-1))
+        total = xv + yv + cv
+        assert K.decrypt_word(s) == total % 16 and int(K.decrypt_bits(co.reshape(1, -1))[0]) == total >> 4
+
+
 def test_schoolbook_and_ntt_bootstrap_identical(O, toy):
     K, ck = toy
     x = K.encrypt_bits(1)
