@@ -117,9 +117,10 @@ def _u32(x):
 def _negacyclic(small, big):
     """small (int64, |.| < 2^8) * big (int32 torus) mod X^N+1 -> int32 with wraparound."""
     N = small.shape[0]
-    full = np.convolve(small.astype(object), big.astype(np.int64).astype(object))  # Python integers: no overflow
-    res = [int(full[i]) - (int(full[i + N]) if i + N < len(full) else 0) for i in range(N)]
-    return _wrap32(np.array([r & 0xFFFFFFFF for r in res], dtype=np.int64))
+    full = np.convolve(small.astype(np.int64), big.astype(np.int64))  # |digit| <= 2^9, |key| < 2^31, N <= 2^10 terms: < 2^51, exact in int64
+    res = full[:N].copy()
+    res[:N - 1] -= full[N:]
+    return _wrap32(res)
 
 
 def _mul_by_xai(p, a):
@@ -212,3 +213,64 @@ def np_add(K, x, y, c, nb_bits):
         axc = np_gate(K, "and", axc, bxc)
         carry = np_gate(K, "xor", carry, axc)
     return out, carry
+
+
+def np_mul32(K, a, b, carry):
+    """Cloud/cloud.c:115-218 `mul32` (nb_bits = 32), gate by gate: for every bit i of b the row a AND b_i, shifted left by i
+    across two 32-bit words (zeros in front are bootsCONSTANT(0) = the noiseless (0, -1/8)), accumulated with `add` -- the low
+    word with carry-in `carry`, the high word with the low word's carry-out.  Returns (high word, low word) like result /
+    result2.  An independent reading, sample for sample, of what oracle/cloud_oracle.c restates."""
+    n = K.n
+    zero = np.zeros(n + 1, dtype=np.int32)
+    zero[n] = -MU
+    lo = np.tile(zero, (32, 1))
+    hi = np.tile(zero, (32, 1))
+    t2 = np.tile(zero, (32, 1))          # tmp3c2 keeps what earlier rounds left beyond `round`: the initial constants
+    for i in range(32):
+        tmp = np.stack([np_gate(K, "and", a[k], b[i]) for k in range(32)])
+        t1 = np.tile(zero, (32, 1))
+        t1[i:] = tmp[:32 - i]
+        t2[:i] = tmp[32 - i:]
+        lo, c1 = np_add(K, lo, t1, carry[0], 32)
+        hi, _ = np_add(K, hi, t2, c1, 32)
+    return hi, lo
+
+
+def _const0(K):
+    z = np.zeros(K.n + 1, dtype=np.int32)
+    z[K.n] = -MU
+    return z
+
+
+def np_mul64(K, a, b, c, carry):
+    """Cloud/cloud.c:220-385 `mul64`: the 64-bit number (b : a) times the 32-bit word c -> (top, mid, low) words.  Per bit i of
+    c the rows a AND c_i and b AND c_i, shifted left by i across three words, accumulated with three chained `add`s."""
+    zero = _const0(K)
+    s1, s2, s3 = (np.tile(zero, (32, 1)) for _ in range(3))
+    t3 = np.tile(zero, (32, 1))           # tmp3c3: entries beyond `round` keep their initial constants
+    for i in range(32):
+        tmp = np.stack([np_gate(K, "and", a[k], c[i]) for k in range(32)])
+        tmp2 = np.stack([np_gate(K, "and", b[k], c[i]) for k in range(32)])
+        c1, c2 = 32 - i, i
+        t1 = np.tile(zero, (32, 1))
+        t1[i:] = tmp[:c1]
+        t2 = np.concatenate([tmp[c1:], tmp2[:c1]])   # the rest of tmp, then what fits of tmp2
+        t3[:c2] = tmp2[c1:]
+        s1, k1 = np_add(K, s1, t1, carry[0], 32)
+        s2, k2 = np_add(K, s2, t2, k1, 32)
+        s3, _ = np_add(K, s3, t3, k2, 32)
+    return s3, s2, s1
+
+
+def np_cloud_mul64(K, w1lo, w1hi, w2lo, w2hi, carry):
+    """main()'s 64-bit MUL branch (cloud.c:2589-2612): two mul64 and `split` (cloud.c:65-113) -> four words, LSW first.
+    split's third add takes the ARRAY carryover2 as an operand: its element 0 is the second add's carry-out, the other 31
+    are still the constants they were initialised to."""
+    r1, r2, r3 = np_mul64(K, w1lo, w1hi, w2lo, carry)
+    r4, r5, r6 = np_mul64(K, w1lo, w1hi, w2hi, carry)
+    s, co = np_add(K, r6, r2, carry[0], 32)
+    s2, co2 = np_add(K, r5, r1, co, 32)
+    carry_array = np.tile(_const0(K), (32, 1))
+    carry_array[0] = co2
+    s3, _ = np_add(K, r4, carry_array, carry[0], 32)
+    return r3, s, s2, s3

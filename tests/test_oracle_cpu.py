@@ -101,6 +101,42 @@ def test_add_circuit_bits_equal_the_independent_restatement(O):
         assert K.decrypt_word(s) == total % 16 and int(K.decrypt_bits(co.reshape(1, -1))[0]) == total >> 4
 
 
+def test_mul32_circuit_bits_equal_the_independent_restatement(O):
+    """orc_mul32 against np_mul32, a second reading of Cloud/cloud.c:115-218 on the independent numpy bootstrap: all 64 output
+    samples identical (11 264 bootstraps on a tiny ring, ~30 s), and they decrypt to the product."""
+    import np_tfhe
+    K = np_tfhe.ToyKeys(n=2, N=32, seed=31)
+    ck = O.CloudKey(K.n, K.N, K.k, K.l, K.Bgbit, K.ks_t, K.ks_basebit, K.bk, K.ksk)
+    av, bv = 0xDEADBEEF, 0x9ABCDEF1
+    a, b = K.encrypt_word(av, 32), K.encrypt_word(bv, 32)
+    carry = K.encrypt_word(0, 32)
+    hi, lo = np_tfhe.np_mul32(K, a, b, carry)
+    r_hi, r_lo = ck.mul32(a, b, carry)
+    assert np.array_equal(hi, r_hi) and np.array_equal(lo, r_lo)
+    assert K.decrypt_word(lo) | (K.decrypt_word(hi) << 32) == av * bv
+
+
+def test_mul64_branch_bits_equal_the_independent_restatement(O):
+    """The oracle's 64-bit MUL branch (orc_cloud_values: two mul64 + split, 35 296 bootstraps) against np_cloud_mul64, a second
+    reading of Cloud/cloud.c:65-113, 220-385 and 2589-2612: the four result words identical, decrypting to the product."""
+    import np_tfhe
+    K = np_tfhe.ToyKeys(n=2, N=32, seed=41)
+    ck = O.CloudKey(K.n, K.N, K.k, K.l, K.Bgbit, K.ks_t, K.ks_basebit, K.bk, K.ksk)
+    av, bv = 0xFEDCBA9876543210, 0x8F1E2D3C4B5A6978
+    S = K.n + 1
+    o1 = np.zeros((8, 32, S), np.int32)
+    o2 = np.zeros((8, 32, S), np.int32)
+    o1[0], o1[1] = K.encrypt_word(av & 0xFFFFFFFF, 32), K.encrypt_word(av >> 32, 32)
+    o2[0], o2[1] = K.encrypt_word(bv & 0xFFFFFFFF, 32), K.encrypt_word(bv >> 32, 32)
+    carry = K.encrypt_word(0, 32)
+    words = np_tfhe.np_cloud_mul64(K, o1[0], o1[1], o2[0], o2[1], carry)
+    rc, out = ck.cloud_values(4, 0, 64, o1, o2, carry)
+    assert rc == 0
+    for w in range(4):
+        assert np.array_equal(words[w], out[w]), w
+    assert sum(K.decrypt_word(words[w]) << (32 * w) for w in range(4)) == av * bv
+
+
 def test_schoolbook_and_ntt_bootstrap_identical(O, toy):
     K, ck = toy
     x = K.encrypt_bits(1)
