@@ -274,3 +274,63 @@ def np_cloud_mul64(K, w1lo, w1hi, w2lo, w2hi, carry):
     carry_array[0] = co2
     s3, _ = np_add(K, r4, carry_array, carry[0], 32)
     return r3, s, s2, s3
+
+
+def np_sub32(K, a, b, carry):
+    """main()'s 32-bit SUB branch (cloud.c:1204-1236): NOT of the second operand (bootsNOT: the sample negated), + 1 through
+    `add` against [bootsCONSTANT(1), 31 x bootsCONSTANT(0)] with a constant-0 carry-in, then a + that with operand 1's carry word."""
+    inverse = _wrap32(-b.astype(np.int64))
+    one = np.tile(_const0(K), (32, 1))
+    one[0, K.n] = MU
+    twos, _ = np_add(K, inverse, one, _const0(K), 32)
+    res, _ = np_add(K, a, twos, carry[0], 32)
+    return res
+
+
+def np_mul128(K, a, b, c, d, e, carry):
+    """Cloud/cloud.c:387-647 `mul128`: the 128-bit number (d : c : b : a) times the 32-bit word e -> five words, TOP first
+    (result .. result5).  Per bit i of e four AND rows, shifted left by i across five words, five chained `add`s."""
+    zero = _const0(K)
+    sums = [np.tile(zero, (32, 1)) for _ in range(5)]
+    t5 = np.tile(zero, (32, 1))           # tmp3c5: entries beyond `round` keep their initial constants
+    for i in range(32):
+        rows = [np.stack([np_gate(K, "and", w[k], e[i]) for k in range(32)]) for w in (a, b, c, d)]
+        c1 = 32 - i
+        t = [np.tile(zero, (32, 1))]
+        t[0][i:] = rows[0][:c1]
+        for q in range(1, 4):
+            t.append(np.concatenate([rows[q - 1][c1:], rows[q][:c1]]))
+        t5[:i] = rows[3][c1:]
+        t.append(t5)
+        cin = carry[0]
+        for q in range(5):
+            sums[q], cin = np_add(K, sums[q], t[q], cin, 32)
+    return sums[4], sums[3], sums[2], sums[1], sums[0]
+
+
+def np_cloud_mul128(K, w1, w2, carry):
+    """main()'s 128-bit MUL branch (cloud.c:2434-2492): four mul128 (operand 1 times each word of operand 2) and fifteen chained
+    adds -- the second and third chains take their carry-in from the TOP carry-out of the chain before (carryover5 -> sum6,
+    carryover10 -> sum11), and the chains' last adds take operand 1's carry word as an operand -> eight words, LSW first."""
+    r = {}
+    for q in range(4):
+        top = np_mul128(K, w1[0], w1[1], w1[2], w1[3], w2[q], carry)
+        for j in range(5):
+            r[5 * q + j + 1] = top[j]      # result1..5, result6..10, ...
+    s, co = {}, {}
+    s[1], co[1] = np_add(K, r[10], r[4], carry[0], 32)
+    s[2], co[2] = np_add(K, r[9], r[3], co[1], 32)
+    s[3], co[3] = np_add(K, r[8], r[2], co[2], 32)
+    s[4], co[4] = np_add(K, r[7], r[1], co[3], 32)
+    s[5], co[5] = np_add(K, r[6], carry, co[4], 32)
+    s[6], co[6] = np_add(K, s[2], r[15], co[5], 32)
+    s[7], co[7] = np_add(K, s[3], r[14], co[6], 32)
+    s[8], co[8] = np_add(K, s[4], r[13], co[7], 32)
+    s[9], co[9] = np_add(K, s[5], r[12], co[8], 32)
+    s[10], co[10] = np_add(K, r[11], carry, co[9], 32)
+    s[11], co[11] = np_add(K, s[7], r[20], co[10], 32)
+    s[12], co[12] = np_add(K, s[8], r[19], co[11], 32)
+    s[13], co[13] = np_add(K, s[9], r[18], co[12], 32)
+    s[14], co[14] = np_add(K, s[10], r[17], co[13], 32)
+    s[15], co[15] = np_add(K, r[16], carry, co[14], 32)
+    return r[5], s[1], s[6], s[11], s[12], s[13], s[14], s[15]

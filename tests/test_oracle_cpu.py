@@ -116,6 +116,23 @@ def test_mul32_circuit_bits_equal_the_independent_restatement(O):
     assert K.decrypt_word(lo) | (K.decrypt_word(hi) << 32) == av * bv
 
 
+def test_sub32_branch_bits_equal_the_independent_restatement(O):
+    """The oracle's 32-bit SUB branch against np_sub32 (cloud.c:1204-1236: bootsNOT, + 1, then the addition), a > b and a < b."""
+    import np_tfhe
+    K = np_tfhe.ToyKeys(n=3, N=64, seed=51)
+    ck = O.CloudKey(K.n, K.N, K.k, K.l, K.Bgbit, K.ks_t, K.ks_basebit, K.bk, K.ksk)
+    S = K.n + 1
+    for av, bv in ((0x1234ABCD, 0x0FEDCBA9), (0x0FEDCBA9, 0x1234ABCD)):
+        o1 = np.zeros((8, 32, S), np.int32)
+        o2 = np.zeros((8, 32, S), np.int32)
+        o1[0], o2[0] = K.encrypt_word(av, 32), K.encrypt_word(bv, 32)
+        carry = K.encrypt_word(0, 32)
+        ref = np_tfhe.np_sub32(K, o1[0], o2[0], carry)
+        rc, out = ck.cloud_values(2, 0, 32, o1, o2, carry)
+        assert rc == 0 and np.array_equal(ref, out[0])
+        assert K.decrypt_word(ref) == (av - bv) % (1 << 32)
+
+
 def test_mul64_branch_bits_equal_the_independent_restatement(O):
     """The oracle's 64-bit MUL branch (orc_cloud_values: two mul64 + split, 35 296 bootstraps) against np_cloud_mul64, a second
     reading of Cloud/cloud.c:65-113, 220-385 and 2589-2612: the four result words identical, decrypting to the product."""
@@ -135,6 +152,30 @@ def test_mul64_branch_bits_equal_the_independent_restatement(O):
     for w in range(4):
         assert np.array_equal(words[w], out[w]), w
     assert sum(K.decrypt_word(words[w]) << (32 * w) for w in range(4)) == av * bv
+
+
+def test_mul128_branch_bits_equal_the_independent_restatement(O):
+    """The oracle's 128-bit MUL branch (four mul128 + fifteen chained adds, 121 184 bootstraps, the false carry dependency
+    between the chains included) against np_cloud_mul128, a second reading of Cloud/cloud.c:387-647 and 2434-2492: all eight
+    result words identical, decrypting to the product.  ~1 min on a tiny ring."""
+    import np_tfhe
+    K = np_tfhe.ToyKeys(n=2, N=32, seed=61)
+    ck = O.CloudKey(K.n, K.N, K.k, K.l, K.Bgbit, K.ks_t, K.ks_basebit, K.bk, K.ksk)
+    av = (1 << 127) | 0xFEDCBA98765432100123456789ABCDEF
+    bv = (1 << 126) | 0x0F1E2D3C4B5A69788796A5B4C3D2E1F0
+    S = K.n + 1
+    o1 = np.zeros((8, 32, S), np.int32)
+    o2 = np.zeros((8, 32, S), np.int32)
+    for w in range(4):
+        o1[w] = K.encrypt_word((av >> (32 * w)) & 0xFFFFFFFF, 32)
+        o2[w] = K.encrypt_word((bv >> (32 * w)) & 0xFFFFFFFF, 32)
+    carry = K.encrypt_word(0, 32)
+    words = np_tfhe.np_cloud_mul128(K, o1[:4], o2[:4], carry)
+    rc, out = ck.cloud_values(4, 0, 128, o1, o2, carry, threads=0)
+    assert rc == 0
+    for w in range(8):
+        assert np.array_equal(words[w], out[w]), w
+    assert sum(K.decrypt_word(words[w]) << (32 * w) for w in range(8)) == av * bv
 
 
 def test_schoolbook_and_ntt_bootstrap_identical(O, toy):
