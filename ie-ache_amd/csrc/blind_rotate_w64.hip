@@ -994,7 +994,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
     __syncthreads();  // the only workgroup barrier
     if (item >= items) return;
     const LaneRoots Rl = make_roots(sTw, lane);
-    const BufRoots<(TWG ? TWG : 1)> Rb{Rl, __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(gtw), (short)0, kTwElems * (int)sizeof(double2), 0x00020000),
+    const BufRoots<(TWG == 2 ? 2 : 1)> Rb{Rl, __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(gtw), (short)0, kTwElems * (int)sizeof(double2), 0x00020000),
                                        lane * (int)sizeof(double2), (512 + (lane & 7)) * (int)sizeof(double2)};
     auto roots = [&]() -> decltype(auto) {
         if constexpr (TWG == 0) return (Rl);
