@@ -299,6 +299,13 @@ def self_launch(args):
     stdout and the ranks' progress on stderr, return the launcher's exit code."""
     import socket
     import subprocess
+    if args.backend == "nccl":
+        import torch  # counting devices does not initialise the GPU in this process
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print("[bench] --gpus %d but this node shows %d GPU(s); one rank per GPU is needed for RCCL "
+                  "(--backend gloo rehearses the flow with ranks sharing a GPU)" % (args.gpus, have), file=sys.stderr)
+            return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

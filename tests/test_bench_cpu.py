@@ -67,9 +67,12 @@ def test_self_launch_builds_a_torchrun_command_and_relays(bench, monkeypatch, ca
     import subprocess
     monkeypatch.setattr(subprocess, "Popen", FakeProc)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "2"])
-    rc = bench.self_launch(types.SimpleNamespace(gpus=3))
+    rc = bench.self_launch(types.SimpleNamespace(gpus=3, backend="gloo"))
     cmd = seen["cmd"]
     assert rc == 7 and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "3"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "3", "--steps", "2"]
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert capsys.readouterr().out == '{"n_gpus": 3}\n'
+    # more RCCL ranks than GPUs on the node: refused before anything is started (this container has no GPU at all)
+    seen.clear()
+    assert bench.self_launch(types.SimpleNamespace(gpus=3, backend="nccl")) == 2 and not seen
