@@ -91,7 +91,7 @@ def pmc_counters(kernel_variant):
         return None
 
 
-def roofline(p, stats, gate_rate, pmc):
+def roofline(p, stats, gate_rate, pmc, launch_kernel=None):
     """The record for one timed leg, for its dominant kernel (the blind rotation).
 
     bound fp64_valu: BK is shared by every gate of a launch out of L2 (hbm_model.reuse_factor), so what limits the
@@ -100,7 +100,9 @@ def roofline(p, stats, gate_rate, pmc):
     own stream, around the kernel's launches only); `frac` = that / the dense FP64 vector peak.  `valu_issue` says how
     full the vector ISSUE slots are (every instruction counted once, whatever it does: FP64 FMAs and adds, index
     arithmetic, cross-lane moves) -- a utilisation of the pipe, not a flop rate.
-    hbm_model is SURVEY 8(d)'s streaming-model figure, priced end to end on the leg's own rate."""
+    hbm_model is SURVEY 8(d)'s streaming-model figure, priced end to end on the leg's own rate.
+    launch_kernel: the kernel this leg's launch size selects (Context.kernel_for_launch); the committed PMC / rocprof
+    evidence is attached only when it was collected on that kernel."""
     bk_b, ksk_b, io_b = algorithmic_bytes(p)
     per_gate = bk_b + ksk_b + io_b
     br_avg_ms = stats.blind_rotate_ms / max(1, stats.blind_rotate_launches)
@@ -110,13 +112,16 @@ def roofline(p, stats, gate_rate, pmc):
     steps_per_launch = p.n / max(1.0, launches_per_gate)
     br_gate_rate = stats.bootstraps / max(1e-9, stats.blind_rotate_ms * 1e-3)   # gates/s of the blind rotation alone
     ks_gate_rate = stats.bootstraps / max(1e-9, stats.keyswitch_ms * 1e-3)
+    pmc_other = None
+    if pmc and launch_kernel and (pmc.get("kernel") or "").split("<")[0] != launch_kernel.split("<")[0]:
+        pmc_other, pmc = pmc, None  # counters of another kernel say nothing about this one
     traffic = pmc["hbm_bytes_per_gate_step"] * gates_per_launch * steps_per_launch if pmc else None
     alg_flop = algorithmic_flops_per_gate(p)
     achieved = br_gate_rate * alg_flop * 1e-12
     out = {"bound": "fp64_valu", "unit": "TFLOP/s", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
            "frac": achieved / FP64_VALU_PEAK_TFLOPS, "frac_algorithmic_flops": achieved / FP64_VALU_PEAK_TFLOPS,
            "traffic": traffic,
-           "kernel": (pmc or {}).get("kernel", "k_blind_rotate"), "avg_launch_ms": br_avg_ms,
+           "kernel": (pmc or {}).get("kernel") or launch_kernel or "k_blind_rotate", "avg_launch_ms": br_avg_ms,
            "gates_per_launch": gates_per_launch, "cmux_steps_per_launch": steps_per_launch,
            "algorithmic_flops_per_gate": alg_flop,
            "algorithmic_flops_per_launch": alg_flop * gates_per_launch * steps_per_launch / p.n,
@@ -126,6 +131,9 @@ def roofline(p, stats, gate_rate, pmc):
            "note": "achieved = SURVEY 8(d) algorithmic flops (8 transforms x 5 M log2 M + 12 M complex MACs per CMux step) of a launch / its "
                    "HIP-event duration; 100 %% = %.0f gates/s per GPU.  rocprof_avg_launch_ms: the same kernel's average in the committed "
                    "rocprofv3 --kernel-trace --stats summary (rocprof_stats), at the geometry named there" % (FP64_VALU_PEAK_TFLOPS * 1e12 / alg_flop)}
+    if pmc_other:
+        out["pmc_note"] = ("launches of %.0f gates take %s; the committed counter passes (%s) were collected on %s, so no traffic / "
+                           "vector-issue figures are attached to this leg" % (gates_per_launch, launch_kernel, pmc_other.get("source"), pmc_other.get("kernel")))
     insts = pmc.get("valu_insts_per_gate_step") if pmc else None
     if insts:
         vi = {"insts_per_gate_step": insts, "fp64_insts_per_gate_step": pmc.get("fp64_insts_per_gate_step", 0),
@@ -440,7 +448,7 @@ def main():
                "gate_ops_per_s": l_rate, "expressions_per_s": lb * world / l_elapsed,
                "per_rank_gate_ops_per_s": [int(linfo.bootstraps) * lb / t for t in l_per_rank],
                "checked": "all %d expressions of the timed pass decrypt to the integer result" % lb,
-               "roofline": roofline(p, lst, l_rate / world, pmc)}
+               "roofline": roofline(p, lst, l_rate / world, pmc, ctx.kernel_for_launch(round(lst.bootstraps / max(1, lst.chunks))))}
         if lb != full_batch:
             rec["sub_batch_of"] = full_batch
             rec["full_share_estimate_s"] = l_elapsed * full_batch / lb
@@ -480,7 +488,7 @@ def main():
                        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
                        "collective_backend": args.backend if world > 1 else None,
                        "per_rank_gate_ops_per_s": [info.bootstraps * batch * args.steps / t for t in per_rank]},
-            "roofline": roofline(p, stats, value / world, pmc),
+            "roofline": roofline(p, stats, value / world, pmc, ctx.kernel_for_launch(round(stats.bootstraps / max(1, stats.chunks)))),
             "fft_guard": fft_guard_record(ctx),
         }
         out.update(leg_out)

@@ -288,6 +288,12 @@ const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx) {
     return ctx->variant.c_str();
 }
 
+const char* ieache_ctx_kernel_for_launch(const ieache_ctx* ctx, int64_t gates) {
+    if (!ctx) return "";
+    const_cast<ieache_ctx*>(ctx)->variant = ctx->eval->kernel_for_launch(gates);
+    return ctx->variant.c_str();
+}
+
 int ieache_circuit_info_get_ex(int kind, int bits, int fold_constants, ieache_circuit_info* out) {
     return guarded([&] {
         if (!out) return fail(IEACHE_EINVAL, "null argument");

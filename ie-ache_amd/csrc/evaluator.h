@@ -97,6 +97,8 @@ public:
     // Returns false for an unknown name or a value out of range.
     bool set_option(const std::string& name, int64_t value);
     std::string kernel_variant() const;
+    // name of the blind-rotation kernel a launch of `gates` gate instances takes under the current options
+    std::string kernel_for_launch(int64_t gates) const;
     // The one-limb blind rotation (k_blind_rotate_w1) rounds sums an FP64 transform carries with ~2^-9 of error instead of
     // provably none; it records how far from an integer its coefficients came.  fft_guard_max(): the largest such distance
     // over the context's life (0.5 would be a wrong bit; the kernel's limit is 1/16); fft_guard_reruns(): calls that crossed

@@ -893,6 +893,25 @@ static void pick_br_variant(const Params& p, const Evaluator::Impl* d, int64_t c
     *slice_out = slice;
 }
 
+std::string Evaluator::kernel_for_launch(int64_t gates) const {
+    if (!d_->use_w64) return "k_blind_rotate_generic";
+    int32_t variant, slice;
+    pick_br_variant(p_, d_, gates < 1 ? 1 : gates, &variant, &slice);
+    char tag[48];
+    snprintf(tag, sizeof tag, "<%d,%d>", (int)p_.l, (int)p_.Bgbit);
+    std::string name;
+    switch (variant) {
+        case w64::kVariantOneLimbDefault: name = "k_blind_rotate_w1b"; break;
+        case w64::kVariantOneLimbTwoWaves: name = "k_blind_rotate_w2r"; break;
+        case w64::kVariantOneLimbFourWaves: name = "k_blind_rotate_w4r"; break;
+        case w64::kVariantWideHandoverOneLimb: name = "k_blind_rotate_wide4"; break;
+        case w64::kVariantWide: name = "k_blind_rotate_wide"; break;
+        case 0: name = "k_blind_rotate_w2"; break;
+        default: snprintf(tag, sizeof tag, "<%d,%d> br_variant %d", (int)p_.l, (int)p_.Bgbit, (int)variant); name = "k_blind_rotate"; break;
+    }
+    return name + tag;
+}
+
 // Runs `items` gate instances described by W (item0 is advanced per chunk).
 static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt,
                                 Torus32* ext, int32_t steps, Torus32* dbg_acc) {

@@ -125,6 +125,8 @@ def lib():
     L.ieache_ctx_fft_audit.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ieache_ctx_kernel_variant.restype = C.c_char_p
     L.ieache_ctx_kernel_variant.argtypes = [vp]
+    L.ieache_ctx_kernel_for_launch.restype = C.c_char_p
+    L.ieache_ctx_kernel_for_launch.argtypes = [vp, C.c_int64]
     L.ieache_circuit_info_get.argtypes = [C.c_int, C.c_int, C.POINTER(CircuitInfo)]
     L.ieache_circuit_info_get_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(CircuitInfo)]
     L.ieache_circuit_level_cap.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]
@@ -258,6 +260,10 @@ class Context:
     @property
     def kernel_variant(self):
         return lib().ieache_ctx_kernel_variant(self.h).decode()
+
+    def kernel_for_launch(self, gates):
+        """Name of the blind-rotation kernel a launch of `gates` gate instances takes."""
+        return lib().ieache_ctx_kernel_for_launch(self.h, int(gates)).decode()
 
     def fft_guard(self):
         """(largest distance to an integer the one-limb blind rotation rounded away -- 0.5 would be a wrong bit --,

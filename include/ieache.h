@@ -187,6 +187,10 @@ int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
  * decrypts to the same bits with fewer bootstraps but is NOT the reference's ciphertext. */
 int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value);
 const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx);
+/* Name of the blind-rotation kernel a launch of `gates` gate instances takes under the context's
+ * current options (launch sizes select different kernels: docs in csrc/blind_rotate_w64.h).  Like
+ * ieache_ctx_kernel_variant the string lives in the context until the next such call. */
+const char* ieache_ctx_kernel_for_launch(const ieache_ctx* ctx, int64_t gates);
 
 /* ------------------------------------------------------------------ *
  * 3. Batch evaluation: `batch` independent expressions through one    *

@@ -47,6 +47,10 @@ def test_roofline_record_from_synthetic_stats(bench, ia):
     assert bench.roofline(p, st2, 1e5, pmc)["valu_issue"]["geometry_differs_from_pmc_run"] is True
     assert r["rocprof_avg_launch_ms"] == 0.82 and r["traffic"] == 1264.0 * 8192 * 15.75
     assert r["hbm_model"]["algorithmic_bytes_per_gate"] == 46480788 and r["hbm_model"]["reuse_factor"] > 10
+    # a leg whose launch size selects another kernel than the one the counters were collected on: no counter figures attached
+    rk = bench.roofline(p, st2, 1e5, pmc, "k_blind_rotate_w2r<3,7>")
+    assert rk["kernel"] == "k_blind_rotate_w2r<3,7>" and "valu_issue" not in rk and rk["traffic"] is None and "pmc_note" in rk
+    assert bench.roofline(p, st, 8192 / 40.8e-3, pmc, pmc["kernel"].split("<")[0] + "<3,7>")["valu_issue"]
     # without committed counters the record still carries the algorithmic fraction
     r0 = bench.roofline(p, st, 8192 / 40.8e-3, None)
     assert r0["frac"] == r["frac"] and "valu_issue" not in r0 and r0["traffic"] is None

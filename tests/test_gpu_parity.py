@@ -1002,7 +1002,14 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
     dev, reruns = ctx.fft_guard()
     assert 0 < dev < 1 / 32 and reruns == reruns0
     assert np.array_equal(kb.dec(results[0][0]), bits[0] ^ bits[1])
-    # a mid-size launch (two waves per gate) and a narrow one (latency kernel) of the same gates
+    # a mid-size launch (two waves per gate) and a narrow one (latency kernel) of the same gates; the names the library
+    # reports for those launch sizes (bench.py labels each leg's roofline record with them)
+    names = [ctx.kernel_for_launch(c).split("<")[0] for c in (200, 400, 900, cnt)]
+    assert names[0] == "k_blind_rotate_wide4" and names[3] == "k_blind_rotate_w1b" and len(set(names)) == 4, names
+    assert ctx.kernel_for_launch(900).endswith("<3,7>")
+    ctx.set_option("exact_fft", 1)
+    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (200, cnt)] == ["k_blind_rotate_wide", "k_blind_rotate_w2"]
+    ctx.set_option("exact_fft", 0)
     mid = ctx.gates(ia.GATE_XOR, a[:900], b[:900])
     assert np.array_equal(mid, results[1][0][:900])
     assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:400], b[:400]), results[1][0][:400])   # four waves per gate (one to two gates per CU)
