@@ -57,6 +57,7 @@ def klass(i):
 
 
 tot = collections.Counter()
+fp64 = collections.Counter()  # FP64 opcodes, weighted: how many of the slots are fused multiply-adds (two flops) and how many one
 print(name)
 for b, ins in blocks.items():
     if b in weights and ins:
@@ -64,8 +65,15 @@ for b, ins in blocks.items():
         print("  block %-12s x%-3g %5d instructions: %s" % (b, weights[b], len(ins), ", ".join("%s %d" % kv for kv in c.most_common())))
         for k, v in c.items():
             tot[k] += v * weights[b]
+        for i in ins:
+            if klass(i) == "FP64 arithmetic":
+                fp64[re.sub(r"_e(32|64)$", "", i.split()[0])] += weights[b]
 valu = sum(v for k, v in tot.items() if k not in ("LDS", "vector memory", "s_waitcnt", "scalar"))
 print("per CMux step:")
 for k, v in tot.most_common():
     print("  %-55s %7.0f" % (k, v))
 print("  %-55s %7.0f" % ("= vector ALU instructions", valu))
+fused = sum(v for k, v in fp64.items() if "fma" in k)
+print("  FP64 by opcode: %s" % ", ".join("%s %.0f" % kv for kv in fp64.most_common()))
+print("  => %.0f fused multiply-adds (2 flop) + %.0f one-flop slots = %.0f flop per lane, %.0f per wave and CMux step"
+      % (fused, sum(fp64.values()) - fused, 2 * fused + sum(fp64.values()) - fused, 64 * (2 * fused + sum(fp64.values()) - fused)))

@@ -251,12 +251,16 @@ static void run(const char* name, int per_iter, int waves_per_simd, double* d_ou
     CHECK(hipEventDestroy(e1));
 }
 
-int main() {
+int main(int argc, char** argv) {
+    // waves per SIMD to measure (default 1 2); 3 and 4 need the 40 KB of LDS per block to fit 3 / 4 times into a CU (they do: 160 KB)
+    std::vector<int> occ;
+    for (int i = 1; i < argc; i++) occ.push_back(atoi(argv[i]));
+    if (occ.empty()) occ = {1, 2};
     double* d_out;
     unsigned long long* d_cyc;
     CHECK(hipMalloc(&d_out, 4096));
     CHECK(hipMalloc(&d_cyc, 64));
-    for (int w = 1; w <= 2; w++) {
+    for (int w : occ) {
 #define T(OP, NAME, N) run<OP>(NAME, N, w, d_out, d_cyc);
         T(0, "v_fma_f64 (3 vgpr srcs)", 16)
         T(14, "v_fmac_f64", 16)
