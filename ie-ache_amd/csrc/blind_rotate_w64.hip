@@ -1286,10 +1286,11 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2r(DevKeys K, const do
     const int32_t* accp = acc + wave * kN;
     uint32_t* accu = reinterpret_cast<uint32_t*>(acc) + wave * kN;
 
-    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
+    int32_t my_a = 0;  // the rotation amounts of 64 steps at a time, one per lane (a launch may be the whole rotation)
 #pragma unroll 1
     for (int32_t i = i0; i < i1; i++) {
-        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
+        if (((i - i0) & 63) == 0) my_a = (i + lane < i1) ? (int32_t)bara[i + lane] : 0;
+        const int32_t a = __builtin_amdgcn_readlane(my_a, (i - i0) & 63);
         if (a == 0) continue;  // workgroup-uniform
         const int bki = i * kStepBytes + wave * L * kRowBytes;  // this wave's rows of BK_i
         double2 s[2][8];
@@ -1466,10 +1467,11 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate_w4r(DevKeys K, const do
     const double2* in_c = light ? (pol == 0 ? sT_all + 3 * kTile : sT_all + 2 * kTile) : nullptr;       // wave 1: tile 3 ; wave 3: tile 2
     double2* scratch = sT_all + (pol == 0 ? 0 : 2) * kTile;  // the heavy partner's tile: after the hand-over only this light wave reads it
 
-    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
+    int32_t my_a = 0;  // the rotation amounts of 64 steps at a time, one per lane (a launch may be the whole rotation)
 #pragma unroll 1
     for (int32_t i = i0; i < i1; i++) {
-        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
+        if (((i - i0) & 63) == 0) my_a = (i + lane < i1) ? (int32_t)bara[i + lane] : 0;
+        const int32_t a = __builtin_amdgcn_readlane(my_a, (i - i0) & 63);
         if (a == 0) continue;  // workgroup-uniform
         const int bki = i * kStepBytes + pol * L * kRowBytes;  // the rows of this wave's polynomial
         double2 s[2][8];
@@ -2671,7 +2673,9 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     const int32_t nsteps = steps < 0 ? p.n : (steps < p.n ? steps : p.n);
     // the wide kernel keeps a slice's rotation amounts in LDS, so a slice may be the whole rotation
     const int32_t max_slice = (variant == kVariantWide || variant == kVariantWide + 1 || (variant >= kVariantWideOneLimb && variant <= kVariantWideOneLimb + 7) ||
-                               variant == kVariantOneLimb + 25 || variant == kVariantOneLimb + 26 || variant == kVariantOneLimb + 28) ? nb : 64;
+                               variant == kVariantOneLimb + 25 || variant == kVariantOneLimb + 26 || variant == kVariantOneLimb + 28 ||
+                               variant == kVariantOneLimbTwoWaves || variant == kVariantOneLimbTwoWaves + 1 ||
+                               variant == kVariantOneLimbFourWaves || variant == kVariantOneLimbFourWaves + 1) ? nb : 64;
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;

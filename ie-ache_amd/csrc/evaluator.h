@@ -85,7 +85,9 @@ public:
     // "ks_batch_min" (same threshold for the compiler-scheduled gate-batched kernel, the cross-check),
     // "ks_split_max" (workgroups the per-gate key switch may cut one gate's walk into when a launch holds only a
     // handful of gates; default 16, 1 = never),
-    // "br_slice" (CMux steps per blind-rotation launch, 1..64),
+    // "br_slice" (CMux steps per blind-rotation launch; 0 = by kernel and launch size: 16 for wide launches that take
+    // several rounds of resident gates, 64 while every gate of the launch is resident at once, the whole rotation for the
+    // four-waves-per-gate and latency kernels),
     // "br_wide_max" (launches of at most this many gate instances use the latency-oriented
     // 2L-waves-per-gate kernel; default = the device's CU count, 0 = never), "br_variant",
     // "exact_fft" (1 = two-limb blind rotation always), "one_limb_min" (launches of at least this many gate

@@ -743,7 +743,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->ks_split_max = (int32_t)value;
     } else if (name == "br_wide_max" && value >= 0) {
         d_->br_wide_max = value;
-    } else if (name == "br_slice" && value >= 1 && value <= 4096) {
+    } else if (name == "br_slice" && value >= 0 && value <= 4096) {  // 0 = by kernel and launch size
         d_->br_slice = (int32_t)value;
     } else if (name == "br_variant" && value >= 0 && value <= 60) {
         d_->br_variant = (int32_t)value;
@@ -885,6 +885,13 @@ static void pick_br_variant(const Params& p, const Evaluator::Impl* d, int64_t c
             // waves per gate finish a step sooner than one
             variant = cnt <= d->four_wave_max ? w64::kVariantOneLimbFourWaves
                       : cnt <= d->two_wave_max ? w64::kVariantOneLimbTwoWaves : w64::kVariantOneLimbDefault;
+            // every gate of such a launch is resident at once, so nothing is gained from short slices (they keep the rounds
+            // of a WIDE launch on the same BK blocks) and each launch boundary costs a tail and a reload of the accumulators:
+            // the whole rotation in one launch for four waves per gate, 64 steps for two (interleaved A/B, profiles/r3_slice_ab.txt)
+            // (likewise one wave per gate while the launch is a single round of 8 gates per CU)
+            if (slice <= 0)
+                slice = variant == w64::kVariantOneLimbFourWaves ? w64::bara_stride(p)
+                        : (variant == w64::kVariantOneLimbTwoWaves || cnt <= 8 * (int64_t)d->cus) ? 64 : slice;
         }
     } else if (d->exact_once && variant >= w64::kVariantOneLimb) {
         variant = 0;

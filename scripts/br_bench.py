@@ -24,6 +24,7 @@ for count in counts:
         if best is None or st.blind_rotate_ms < best.blind_rotate_ms:
             best = st
     ok = np.array_equal(tools.decrypt_bits(p, k["lwe_key"], out), bits[0][:count] & bits[1][:count])
-    print("variant", os.environ.get("BR_VARIANT", os.environ.get("IEACHE_BR_VARIANT", "0")), "slice", os.environ.get("BR_SLICE", "16"), ctx.kernel_variant, "count", count, "ok", ok,
-          "BR ms %.2f (%.0f gates/s)  KS ms %.2f (%.0f gates/s)" % (best.blind_rotate_ms, count / best.blind_rotate_ms * 1e3,
+    print("variant", os.environ.get("BR_VARIANT", os.environ.get("IEACHE_BR_VARIANT", "0")), "slice", os.environ.get("BR_SLICE", "auto"), ctx.kernel_variant, "count", count, "ok", ok,
+          "BR ms %.2f in %d launches of %s (%.0f gates/s)  KS ms %.2f (%.0f gates/s)" % (best.blind_rotate_ms, best.blind_rotate_launches,
+          ctx.kernel_for_launch(count).split("<")[0], count / best.blind_rotate_ms * 1e3,
           best.keyswitch_ms, count / best.keyswitch_ms * 1e3), "guard", ctx.fft_guard(), flush=True)

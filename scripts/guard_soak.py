@@ -14,7 +14,9 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 p = ia.default_params()
 k = tools.keygen_raw(p, (314, 1592, 657))
 ctx = ia.Context.from_arrays(p, k["bk"], k["ksk"])
-rng = np.random.default_rng(2026)
+if os.environ.get("FFT_AUDIT"):  # e.g. FFT_AUDIT=1: every one-limb launch re-runs 64 of its gates on the two-limb kernel and compares bits
+    ctx.set_option("fft_audit", int(os.environ["FFT_AUDIT"]))
+rng = np.random.default_rng(int(os.environ.get("SEED", "2026")))
 total = 0
 for it in range(passes):
     kind = (ia.CIRC_MUL_WALLACE, ia.CIRC_MUL)[it % 2]

@@ -713,7 +713,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     for sl in (1, 5, 16, 64):                              # n=16: 16, 4, 1, 1 launches; 5 leaves a ragged last slice
         ctx.set_option("br_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref), sl
-    ctx.set_option("br_slice", 16)
+    ctx.set_option("br_slice", 0)
     for variant in (2, 3, 5, 6, 10, 11, 12):                   # workgroup-barrier sync; cross-lane (DPP/permlane) transposes: both /
         ctx.set_option("br_variant", variant)              # lane-high only / lane-low only; stores interleaved with multiplies
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:300], b[:300]), ref[:300]), variant
@@ -721,7 +721,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     for sl in (16, 5, 4096):                               # sliced, ragged, whole rotation in one launch
         ctx.set_option("br_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:600], b[:600]), ref[:600]), sl
-    ctx.set_option("br_slice", 16)
+    ctx.set_option("br_slice", 0)
     # one wave per gate on the one-limb spectrum (the default for wide launches, which `ref` above took): with and without
     # the guard arithmetic, forward transposes through LDS / cross-lane, early BK requests; ragged last workgroup of 4 gates
     # 20 / 21: two waves per gate on the one-limb spectrum; 22 / 23: 2L waves, a row each; 24-28: the latency kernel on one limb
@@ -736,7 +736,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         for sl in (1, 5, 64):
             ctx.set_option("br_slice", sl)
             assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), (variant, sl)
-    ctx.set_option("br_slice", 16)
+    ctx.set_option("br_slice", 0)
     ctx.set_option("br_variant", 0)
     dev, reruns = ctx.fft_guard()
     assert 0 < dev < 1 / 16 and reruns == 0                # rounding stayed far from the 0.5 that would flip a bit
