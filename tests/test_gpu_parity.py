@@ -1012,12 +1012,15 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
     ctx.set_option("exact_fft", 0)
     mid = ctx.gates(ia.GATE_XOR, a[:900], b[:900])
     assert np.array_equal(mid, results[1][0][:900])
-    assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:400], b[:400]), results[1][0][:400])   # four waves per gate (one to two gates per CU)
-    assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:200], b[:200]), results[1][0][:200])
-    # ... and the mid-size kernel (k_blind_rotate_w2r, 257 .. 1 024 gates per launch) against the ORACLE itself at n = 630:
+    four = ctx.gates(ia.GATE_XOR, a[:400], b[:400])      # four waves per gate (one to two gates per CU), whole rotation in one launch
+    narrow = ctx.gates(ia.GATE_XOR, a[:200], b[:200])    # the latency kernel
+    assert np.array_equal(four, results[1][0][:400]) and np.array_equal(narrow, results[1][0][:200])
+    # ... and each of those launch-size regimes (k_blind_rotate_w2r, _w4r, _wide4) against the ORACLE itself at n = 630:
     # 640 of those 900 gates, the oracle's exact back-end on all host cores (~0.3 s per gate and core)
     ref = kb.ck.gates_batch("xor", a[:640], b[:640], threads=0)
     assert np.array_equal(ref, mid[:640])
+    assert np.array_equal(ref[:400], four) and np.array_equal(ref[:200], narrow)
+    assert np.array_equal(ref, results[0][0][:640])      # and the wide-launch kernel's first level
 
 
 def test_full_config_add16_batch4096_decrypts(ia, gpu_ctx):
