@@ -272,17 +272,17 @@ def check_outputs(tools, p, lwe_key, kind, bits, inb, d_out, rank):
 
 def timed(torch, dist, world, dev, backend, fn):
     """barrier + synchronize on both sides, MAX over ranks"""
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fn()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     per_rank = [elapsed]
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -384,7 +384,7 @@ def main():
     bdev = dev if args.backend == "nccl" else torch.device("cpu")
     d_bk, d_ksk, d_key = (t.to(dev) for t in parallel.broadcast_cloud_key(p, keys, bdev, dist))
     torch.cuda.synchronize()
-    t_bcast = time.perf_counter() - t0 if world > 1 else 0.0
+    t_bcast = time.perf_counter() - t0 if dist is not None else 0.0
     lwe_key = d_key.cpu().numpy()
     ctx = ia.Context.from_device_pointers(p, d_bk.data_ptr(), d_ksk.data_ptr(), device=local_rank)
     del d_bk, d_ksk
@@ -428,7 +428,7 @@ def main():
         # one decision for all ranks (the pass contains barriers): skip a leg the time box has no room for
         estimate = int(linfo.bootstraps) * lb / max(1.0, primary_rate / world)
         so_far = time.perf_counter() - T_START
-        if world > 1:
+        if dist is not None:
             t = torch.tensor([so_far], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             so_far = float(t.item())
@@ -485,8 +485,8 @@ def main():
                                      "exact transform, which exact_fft=1 selects; fft_guard below)",
                        "parallelism": "batch-sharded x%d" % world, "kernel": ctx.kernel_variant,
                        "key_broadcast_s": round(t_bcast, 4),
-                       "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
-                       "collective_backend": args.backend if world > 1 else None,
+                       "rccl_ranks": world if (dist is not None and args.backend == "nccl") else 0,
+                       "collective_backend": args.backend if dist is not None else None,
                        "per_rank_gate_ops_per_s": [info.bootstraps * batch * args.steps / t for t in per_rank]},
             "roofline": roofline(p, stats, value / world, pmc, ctx.kernel_for_launch(round(stats.bootstraps / max(1, stats.chunks)))),
             "fft_guard": fft_guard_record(ctx),
@@ -502,7 +502,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(p, keys, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -16,11 +16,19 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    # IEACHE_DIST_SINGLE=1: a process group of ONE rank, so that a one-GPU box runs the same collective calls
+    # (RCCL initialisation with device_id, device-side broadcast / all_gather / all_reduce, barrier) the N > 1 job makes
+    single = world == 1 and os.environ.get("IEACHE_DIST_SINGLE") == "1"
+    if world == 1 and not single:
         return rank, world, local_rank, None
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if single and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}

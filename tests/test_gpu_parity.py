@@ -1296,3 +1296,25 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     assert m["folded"]["executed_bootstraps_per_expr"] == 7568 and m["carry_save"]["levels"] == 37
     ma = out["muladd64"]
     assert ma["batch_per_gpu"] == 2 and ma["bootstraps_per_expr"] == 35936 and ma["roofline"]["frac"] > 0 and "mul128" not in out
+
+
+@pytest.mark.gpu
+def test_bench_collectives_on_rccl_with_one_rank(tmp_path):
+    """The collective calls of the N>1 job on RCCL itself, as far as one GPU allows: IEACHE_DIST_SINGLE=1 makes bench.py
+    form a process group of ONE rank on backend "nccl" (= RCCL), so init_process_group(device_id=...), the device-side
+    broadcast of BK / KSK / the LWE key, the barriers, all_gather and all_reduce of the timing path all run on the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "64",
+           "--backend", "nccl", "--no-cpu-baseline", "--legs", "mul32", "--mul32-batch", "4"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp_path,
+                       env=dict(env, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", IEACHE_DIST_SINGLE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and cfg["rccl_ranks"] == 1 and cfg["collective_backend"] == "nccl" and cfg["key_broadcast_s"] > 0
+    assert len(cfg["per_rank_gate_ops_per_s"]) == 1 and out["value"] > 0 and out["mul32"]["mul32_per_s"] > 0

@@ -80,3 +80,30 @@ def test_two_rank_gloo_broadcast_and_shard(tmp_path):
         outs.append(out)
     assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
     assert "MULTIRANK_OK" in outs[0]
+
+
+def test_single_rank_process_group_option(tmp_path):
+    """IEACHE_DIST_SINGLE=1: a process group of one rank (how a one-GPU box rehearses the collective calls on RCCL);
+    here on gloo: the broadcast and the host-side gather go through torch.distributed instead of being skipped."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import ieache_amd as ia\n"
+        "from ieache_amd import parallel\n"
+        "import torch\n"
+        "rank, world, local, dist = parallel.init_distributed('gloo')\n"
+        "assert (rank, world) == (0, 1) and dist is not None and dist.is_initialized() and dist.get_world_size() == 1\n"
+        "p = ia.default_params().copy(n=7, N=32)\n"
+        "keys = {'bk': np.arange(p.bk_count, dtype=np.int32), 'ksk': np.arange(p.ksk_count, dtype=np.int32), 'lwe_key': np.ones(p.n, dtype=np.int32)}\n"
+        "bk, ksk, key = parallel.broadcast_cloud_key(p, keys, torch.device('cpu'), dist)\n"
+        "assert bk.numel() == p.bk_count and int(bk[-1]) == p.bk_count - 1 and int(key.sum()) == p.n\n"
+        "g = parallel.gather_to_rank0(dist, np.arange(6).reshape(3, 2))\n"
+        "assert g.shape == (3, 2)\n"
+        "dist.destroy_process_group()\n"
+        "print('single-rank ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=tmp_path,
+                       env=dict(env, IEACHE_DIST_SINGLE="1"))
+    assert r.returncode == 0 and "single-rank ok" in r.stdout, r.stderr[-2000:]
