@@ -79,7 +79,8 @@ def pmc_counters(kernel_variant):
                "hbm_bytes_per_gate_step": tj["hbm_bytes_per_gate_step"], "l2_hit_rate": tj.get("l2_hit_rate"),
                "source": tj.get("pmc_summary", tj.get("source")), "shader_cycles_per_gate_step": tj.get("shader_cycles_per_gate_step"),
                "gates_per_launch": tj.get("gates_per_launch"), "cmux_steps_per_launch": tj.get("cmux_steps_per_launch"),
-               "rocprof_avg_launch_ms": tj.get("rocprof_avg_launch_ms"), "rocprof_stats": tj.get("rocprof_stats")}
+               "rocprof_avg_launch_ms": tj.get("rocprof_avg_launch_ms"), "rocprof_stats": tj.get("rocprof_stats"),
+               "issue_model": tj.get("issue_model")}
         summ = tj.get("pmc_summary")
         if summ:
             for line in open(os.path.join(ROOT, summ)):
@@ -154,6 +155,13 @@ def roofline(p, stats, gate_rate, pmc, launch_kernel=None):
             ghz = cyc * gates_per_launch * steps_per_launch / (br_avg_ms * 1e-3) / 1e9
             vi["effective_clock_GHz"] = ghz
             vi["utilisation_at_effective_clock"] = vi["utilisation"] * 2.4 / ghz
+        im = pmc.get("issue_model")
+        if im and im.get("issue_bound_gates_per_s"):
+            # the kernel's own instruction stream priced at measured per-instruction issue times (two waves per SIMD): how close
+            # the launch comes to what its instructions cost, as opposed to the nominal 4-cycle slots above
+            vi["issue_bound_gates_per_s"] = im["issue_bound_gates_per_s"]
+            vi["frac_of_issue_bound"] = br_gate_rate / im["issue_bound_gates_per_s"]
+            vi["issue_model"] = {k: im[k] for k in ("ns_per_fp64_slot", "ns_per_other_vector_slot", "source") if k in im}
         out["valu_issue"] = vi
     measured_gbs = (traffic / (br_avg_ms * 1e-3) / 1e9) if (traffic and br_avg_ms > 0) else None
     alg_launch = per_gate * gates_per_launch * steps_per_launch / p.n

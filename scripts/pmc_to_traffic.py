@@ -59,6 +59,16 @@ out.update({
         "l2_hit_rate": vals[("KS", "TCC_HIT_sum")] / (vals[("KS", "TCC_HIT_sum")] + vals[("KS", "TCC_MISS_sum")]),
     },
 })
+# Issue bound of the kernel's own instruction stream: its vector instructions priced at the wall time a stream of such
+# instructions takes per wave-instruction and SIMD with two waves per SIMD (scripts/ubench/valu_rates.hip,
+# profiles/r3_issue_costs.txt: FP64 arithmetic / conversions ~5.3 'cycles at 2.4 GHz' = 2.21 ns, the other vector
+# instructions ~4.5 = 1.875 ns; already at the clock the chip holds under FP64 load)
+if key == "w1x64-radix8-onelimb":
+    e = out[key]
+    fp64, other = e["fp64_insts_per_gate_step"], e["valu_insts_per_gate_step"] - e["fp64_insts_per_gate_step"]
+    t = fp64 * 2.21e-9 + other * 1.875e-9
+    e["issue_model"] = {"ns_per_fp64_slot": 2.21, "ns_per_other_vector_slot": 1.875, "gate_step_ns_of_one_simd": t * 1e9,
+                        "issue_bound_gates_per_s": 256 * 4 / (t * 630), "source": "profiles/r3_issue_costs.txt (two waves per SIMD)"}
 # the rocprofv3 --kernel-trace --stats average of the same kernel (primary bench leg alone), if the caller names the file
 for a in sys.argv[5:]:
     if a.startswith("stats="):

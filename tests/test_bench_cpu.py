@@ -42,6 +42,10 @@ def test_roofline_record_from_synthetic_stats(bench, ia):
     assert abs(r["cmux_steps_per_launch"] - 15.75) < 1e-9 and r["gates_per_launch"] == 8192
     vi = r["valu_issue"]
     assert abs(vi["utilisation"] - rate * 3158.0 * 630 / (256 * 4 * 2.4e9 / 4)) < 1e-12 and vi["utilisation"] < 1
+    assert "issue_bound_gates_per_s" not in vi  # no issue model in this synthetic counter record
+    pmc_im = dict(pmc, issue_model={"issue_bound_gates_per_s": 240000.0, "ns_per_fp64_slot": 2.21, "ns_per_other_vector_slot": 1.875, "source": "s"})
+    vim = bench.roofline(p, st, 8192 / 40.8e-3, pmc_im)["valu_issue"]
+    assert abs(vim["frac_of_issue_bound"] - rate / 240000.0) < 1e-12 and vim["issue_model"]["ns_per_fp64_slot"] == 2.21
     assert vi["geometry_differs_from_pmc_run"] is False  # 8 192 gates, slices of 16 steps (15.75 on average: the last one is short)
     st2 = types.SimpleNamespace(**dict(vars(st), bootstraps=4096))
     assert bench.roofline(p, st2, 1e5, pmc)["valu_issue"]["geometry_differs_from_pmc_run"] is True
