@@ -18,7 +18,10 @@ void prepare_spectrum(const Params& p, const Torus32* d_bk_raw, double2* d_bkf, 
 // bytes of blind-rotation state (accumulator + rotation amounts) one gate instance keeps in HBM between slices
 size_t state_bytes_per_item(const Params& p);
 // K0..K4 for `items` gate instances: prologue, then the CMux steps in slices of S steps per launch
-// (`slice`, 1..64; 0 = default 16 or IEACHE_BR_SLICE).  state: items * state_bytes_per_item() bytes of scratch.
+// (`slice`: 1..64 for the one-wave-per-gate kernels, up to the whole rotation for k_blind_rotate_w2r / _w4r / _wide*, which
+// reload their per-lane rotation amounts every 64 steps or keep them in LDS; out of range or 0 = default 16 or
+// IEACHE_BR_SLICE; the evaluator passes 64 / the whole rotation for launches whose gates are all resident at once).
+// state: items * state_bytes_per_item() bytes of scratch.
 // ext rows of N+4 int32 (may be null), dbg_acc [items][2][N] (may be null; when set, pass ext = null).
 // Returns the number of k_blind_rotate_w2 launches issued.
 // d_bkf1 / guard: the one-limb spectrum and the two-word guard record of k_blind_rotate_w1 (may be null for the
