@@ -72,7 +72,8 @@ class CircuitInfo(C.Structure):
 
 
 def library_path():
-    return os.path.join(_PKG, "libieache.so")
+    # IEACHE_LIBRARY: another build of the same library (A/B of compiler flags: scripts/build_alt.sh)
+    return os.environ.get("IEACHE_LIBRARY") or os.path.join(_PKG, "libieache.so")
 
 
 def build_library(jobs=4):
