@@ -246,6 +246,11 @@ CLOUD_N630_CASES = (
     ("mul32", 4, 32, (0, 0xC0FFEE11, 4105), (0, 0x89ABCDEF, 4106)),
     ("add64", 1, 64, (0, 0xFEDCBA9876543210, 4107), (0, 0x0123456789ABCDEF, 4108)),                    # sum = 2^64 - 1: every sum bit set, no carry out
     ("sub32_borrow", 2, 32, (0, 0x0FEDCBA9, 4109), (0, 0x1234ABCD, 4110)),                               # a < b: two's complement result
+    # the sign branches of main() (cloud.c:812-821, 870, 1194-1196, 1809): process.c's sign code 2 = negative
+    ("add32_first_negative", 1, 32, (2, 0x0BADF00D, 4111), (0, 0x1234ABCD, 4112)),                       # (-A)+B runs B-A
+    ("sub64_second_negative", 2, 64, (0, 0x0123456789ABCDEF, 4113), (2, 0x0FEDCBA987654321, 4114)),      # A-(-B) runs A+B
+    ("add128_both_negative", 1, 128, (2, 0x0123456789ABCDEF0FEDCBA987654321, 4115), (2, 0x01111111222222223333333344444444, 4116)),  # -(A+B): ADD, total negatives 4
+    ("sub32_both_negative", 2, 32, (2, 0x0FEDCBA9, 4117), (2, 0x1234ABCD, 4118)),                        # (-A)-(-B) runs B-A
 )
 CLOUD_N630_KEY_SEED, CLOUD_N630_NBIT_SEED = (314, 1592, 657), (2718, 2818)
 
@@ -289,10 +294,13 @@ def cloud_n630(only=None):
             ref = np.ascontiguousarray(ref.reshape(288, S))
             nw = (2 * bits if op == 4 else bits) // 32
             val = tools.bits_to_int(tools.decrypt_bits(p, lwe_key, ref[:32 * nw]))
-            exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 4: a * b}[op]
+            # which circuit main() runs on the magnitudes (cloud.c:870, 1194-1196, 1809): ADD, A-B or B-A
+            run = 4 if op == 4 else {(1, 0): 1, (1, 3): 1, (1, 2): 2, (1, 1): 3, (2, 1): 1, (2, 2): 1, (2, 0): 2, (2, 3): 3}[(op, neg)]
+            exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 3: (b - a) % (1 << bits), 4: a * b}[run]
             assert val == exp, (name, hex(val), hex(exp))
-            if op == 2 and a < b:
-                exp = a - b  # what verif.c reads: two's complement (verif.c:733-789)
+            if op != 4:  # what verif.c reads back (verif.c:120-179, 733-789): the signed result of the signed operands
+                sgn_a, sgn_b = (-a if sa else a), (-b if sb else b)
+                exp = sgn_a + sgn_b if op == 1 else sgn_a - sgn_b
             out["cases"][name] = {"operator": op, "bits": bits, "a": a, "sign_a": sa, "seed_a": seed_a, "b": b, "sign_b": sb,
                                   "seed_b": seed_b, "cloud_data_sha256": digest(data), "value_samples_sha256": digest(ref),
                                   "first_value_sample": ref[0].tolist(), "last_value_sample": ref[-1].tolist(),
