@@ -251,6 +251,10 @@ CLOUD_N630_CASES = (
     ("sub64_second_negative", 2, 64, (0, 0x0123456789ABCDEF, 4113), (2, 0x0FEDCBA987654321, 4114)),      # A-(-B) runs A+B
     ("add128_both_negative", 1, 128, (2, 0x0123456789ABCDEF0FEDCBA987654321, 4115), (2, 0x01111111222222223333333344444444, 4116)),  # -(A+B): ADD, total negatives 4
     ("sub32_both_negative", 2, 32, (2, 0x0FEDCBA9, 4117), (2, 0x1234ABCD, 4118)),                        # (-A)-(-B) runs B-A
+    # the widest operands the contract carries: all eight words of each operand, eight result words
+    ("add256", 1, 256, (0, 0x0123456789ABCDEF0FEDCBA98765432100112233445566778899AABBCCDDEEFF, 4119),
+     (0, 0x0EDCBA9876543210F0123456789ABCDEFFEEDDCCBBAA99887766554433221100, 4120)),
+    ("sub128", 2, 128, (0, 0x80000000000000000000000000000001, 4121), (0, 0x00000000FFFFFFFFFFFFFFFF00000002, 4122)),   # borrows across word boundaries
 )
 CLOUD_N630_KEY_SEED, CLOUD_N630_NBIT_SEED = (314, 1592, 657), (2718, 2818)
 

@@ -639,7 +639,7 @@ def test_cloud_file_contract_at_product_parameters(ia, tmp_path):
     """The ./cloud process contract at n=630 (cloud.c:650-917), through the `cloud` EXECUTABLE: keygen from the documented
     seeds, `alice` twice, operator.txt, ./cloud in that directory, `verif` -- BASELINE configs[0] (16-bit a+b, zero-extended in
     the 32-bit word), 32-bit SUBs (a > b and a < b), a 64-bit ADD, a 32-bit MUL, and the sign branches of main() (first /
-    second / both operands negative: (-A)+B as B-A, A-(-B) as A+B at 64 bits, -(A+B) at 128 bits, (-A)-(-B) as B-A).  2536-byte samples, the 114 MB key file through the codec, the fast
+    second / both operands negative: (-A)+B as B-A, A-(-B) as A+B at 64 bits, -(A+B) at 128 bits, (-A)-(-B) as B-A), a 256-bit ADD and a 128-bit SUB with borrows across words.  2536-byte samples, the 114 MB key file through the codec, the fast
     kernels behind ieache_cloud_run; the 288 value samples of answer.data equal what the oracle's orc_cloud_values made of
     the same cloud.data (tests/golden/cloud_n630.json, make_golden.py cloud_n630).  A 256-bit MUL exits 126 and leaves
     exactly the 162 304 bytes the reference's caller tests for (Cloud/dragonfly_cipher_cloud.py:1295, cloud.c:860-864)."""
