@@ -23,6 +23,8 @@ __global__ __launch_bounds__(256) void k_rate(double* out, unsigned long long* c
     __shared__ __align__(16) double2 lds[4 * 640];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double a[8], b[8], c[8];
+    typedef double d4v __attribute__((ext_vector_type(4)));
+    d4v acc[4] = {};
     int ia[8], ib[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -206,6 +208,24 @@ __global__ __launch_bounds__(256) void k_rate(double* out, unsigned long long* c
 #define M(i) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_add_u32 %2, %2, %0" : "+v"(ia[i]), "+v"(ib[i]), "+v"(ia[(i + 4) & 7]));
             R8(M)
 #undef M
+        } else if constexpr (OP == 35) {  // v_mfma_f64_16x16x4_f64 alone: 16 instructions, four independent accumulators
+#define X(j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b[j], acc[j], 0, 0, 0);
+            X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
+#undef X
+        } else if constexpr (OP == 36) {  // ... each followed by four independent v_fma_f64: 16 MFMA + 64 FMA (do the two pipes overlap?)
+#define X(j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b[j], acc[j], 0, 0, 0);
+#define M(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[4 + (i & 3)]) : "v"(b[i]), "v"(c[i]));
+#define G(j) X(j) M(0) M(1) M(2) M(3)
+            G(0) G(1) G(2) G(3) G(0) G(1) G(2) G(3) G(0) G(1) G(2) G(3) G(0) G(1) G(2) G(3)
+#undef G
+#undef M
+#undef X
+        } else if constexpr (OP == 37) {  // the 64 v_fma_f64 of OP 36 without the MFMAs
+#define M(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[4 + (i & 3)]) : "v"(b[i]), "v"(c[i]));
+#define G(j) M(0) M(1) M(2) M(3)
+            G(0) G(1) G(2) G(3) G(0) G(1) G(2) G(3) G(0) G(1) G(2) G(3) G(0) G(1) G(2) G(3)
+#undef G
+#undef M
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -216,6 +236,7 @@ __global__ __launch_bounds__(256) void k_rate(double* out, unsigned long long* c
         s += a[i] + b[i];
         si += ia[i] + ib[i];
     }
+    s += acc[0].x + acc[1].y + acc[2].z + acc[3].w;
     if (s == 12345.678 || si == 0x7fffffff) out[tid] = s + si;
     if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
@@ -297,6 +318,9 @@ int main(int argc, char** argv) {
         T(22, "ds_read_b32", 16)
         T(23, "ds_add_u32", 16)
         T(27, "mix 12 v_fma_f64 + 4 ds_read_b128", 16)
+        T(35, "v_mfma_f64_16x16x4_f64", 16)
+        T(36, "16 v_mfma_f64_16x16x4 + 64 v_fma_f64 (per 80)", 80)
+        T(37, "the 64 v_fma_f64 of that mix alone", 64)
 #undef T
     }
     return 0;

@@ -255,6 +255,7 @@ CLOUD_N630_CASES = (
     ("add256", 1, 256, (0, 0x0123456789ABCDEF0FEDCBA98765432100112233445566778899AABBCCDDEEFF, 4119),
      (0, 0x0EDCBA9876543210F0123456789ABCDEFFEEDDCCBBAA99887766554433221100, 4120)),
     ("sub128", 2, 128, (0, 0x80000000000000000000000000000001, 4121), (0, 0x00000000FFFFFFFFFFFFFFFF00000002, 4122)),   # borrows across word boundaries
+    ("mul64_second_negative", 4, 64, (0, 0xFEDCBA9876543210, 4123), (2, 0x0123456789ABCDEF, 4124)),   # split / mul32 x4 / recombination (cloud.c:220-385); ~45 min of oracle on 8 cores
 )
 CLOUD_N630_KEY_SEED, CLOUD_N630_NBIT_SEED = (314, 1592, 657), (2718, 2818)
 
@@ -302,6 +303,8 @@ def cloud_n630(only=None):
             run = 4 if op == 4 else {(1, 0): 1, (1, 3): 1, (1, 2): 2, (1, 1): 3, (2, 1): 1, (2, 2): 1, (2, 0): 2, (2, 3): 3}[(op, neg)]
             exp = {1: (a + b) % (1 << bits), 2: (a - b) % (1 << bits), 3: (b - a) % (1 << bits), 4: a * b}[run]
             assert val == exp, (name, hex(val), hex(exp))
+            if op == 4 and neg in (1, 2):
+                exp = -exp  # verif.c:1409-1435
             if op != 4:  # what verif.c reads back (verif.c:120-179, 733-789): the signed result of the signed operands
                 sgn_a, sgn_b = (-a if sa else a), (-b if sb else b)
                 exp = sgn_a + sgn_b if op == 1 else sgn_a - sgn_b
