@@ -318,6 +318,53 @@ def cloud_n630(only=None):
     print("cloud_n630.json written")
 
 
+CLOUD_N630_CHAIN = {"first": "add64", "operator": 2, "c": 0xFF00FF00FF00FF00, "seed_c": 4131}  # (2^64 - 1) - c stays below 2^63: verif.c reads SUB results as two's complement
+
+
+def cloud_n630_chain():
+    """compute() followed by compute_final() through the FILE boundary at the product parameter set
+    (Cloud/dragonfly_cipher_cloud.py:1219-1327): stage 1 = the `add64` case above, then the third operand alone in
+    cloud.data, answer.data spliced in front of it (flip) and ./cloud run again with operator SUB: (a + b) - c.
+    The second run's operand words are the first run's value samples and the carry-word filler, so its 288 value
+    samples are fixed too; committed: their sha256, first / last sample, the integer verif reads.  ~5 min on 8 cores."""
+    import tempfile
+    import time
+    p = ia.default_params()
+    S = p.n + 1
+    path = os.path.join(HERE, "cloud_n630.json")
+    out = json.load(open(path))
+    first = next(c for c in CLOUD_N630_CASES if c[0] == CLOUD_N630_CHAIN["first"])
+    name, op, bits, (sa, a, seed_a), (sb, b, seed_b) = first
+    with tempfile.TemporaryDirectory() as d:
+        t0 = time.time()
+        tools.keygen_files(d, p, seed=CLOUD_N630_KEY_SEED, nbit_seed=CLOUD_N630_NBIT_SEED)
+        _, bk, ksk = tools.read_cloud_key(os.path.join(d, "cloud.key"))
+        _, lwe_key, _ = tools.read_secret_key(os.path.join(d, "secret.key"))
+        ck = O.CloudKey(p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, bk, ksk)
+        tools.alice(d, sa, bits, a, seed=seed_a)
+        tools.alice(d, sb, bits, b, seed=seed_b, append=True)
+        w = tools.read_samples(os.path.join(d, "cloud.data"), p.n).reshape(22, 32, S)
+        rc, ref1 = ck.cloud_values(op, 0, bits, np.ascontiguousarray(w[2:10]), np.ascontiguousarray(w[13:21]), np.ascontiguousarray(w[10]), threads=0)
+        ref1 = np.ascontiguousarray(ref1.reshape(288, S))
+        assert rc == 0 and digest(ref1) == out["cases"][name]["value_samples_sha256"]
+        # stage 2: answer.data = [neg, bit, r1..r8, filler] in front of the third operand's 11 words
+        c, seed_c, op2 = CLOUD_N630_CHAIN["c"], CLOUD_N630_CHAIN["seed_c"], CLOUD_N630_CHAIN["operator"]
+        tools.alice(d, 0, bits, c, seed=seed_c)
+        wc = tools.read_samples(os.path.join(d, "cloud.data"), p.n).reshape(11, 32, S)
+        r = ref1.reshape(9, 32, S)
+        rc, ref2 = ck.cloud_values(op2, 0, bits, np.ascontiguousarray(r[:8]), np.ascontiguousarray(wc[2:10]), np.ascontiguousarray(r[8]), threads=0)
+        ref2 = np.ascontiguousarray(ref2.reshape(288, S))
+        assert rc == 0
+        val = tools.bits_to_int(tools.decrypt_bits(p, lwe_key, ref2[:bits]))
+        assert val == (a + b - c) % (1 << bits), hex(val)
+        out["chain"] = dict(CLOUD_N630_CHAIN, bits=bits, value_samples_sha256=digest(ref2), first_value_sample=ref2[0].tolist(),
+                            last_value_sample=ref2[-1].tolist(), expect=a + b - c, oracle_seconds=round(time.time() - t0, 1),
+                            note="compute(ADD) on the `add64` case, then compute_final(SUB, flip=True) with the third operand c")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+    print("cloud_n630.json: chain written in %.0f s" % (time.time() - t0))
+
+
 def plaintext_kats():
     kats = []
     for bits in (32, 64, 128, 256):
@@ -346,6 +393,8 @@ if __name__ == "__main__":
         mul128_n630()
     elif sys.argv[1:] == ["misc_n630"]:      # ~6 min
         misc_n630()
+    elif sys.argv[1:] == ["cloud_n630_chain"]:  # ~5 min
+        cloud_n630_chain()
     elif sys.argv[1:2] == ["cloud_n630"]:    # ~15 min on 8 cores; optional case names after it
         cloud_n630(sys.argv[2:] or None)
     else:

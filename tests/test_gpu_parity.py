@@ -639,7 +639,8 @@ def test_cloud_file_contract_at_product_parameters(ia, tmp_path):
     """The ./cloud process contract at n=630 (cloud.c:650-917), through the `cloud` EXECUTABLE: keygen from the documented
     seeds, `alice` twice, operator.txt, ./cloud in that directory, `verif` -- BASELINE configs[0] (16-bit a+b, zero-extended in
     the 32-bit word), 32-bit SUBs (a > b and a < b), a 64-bit ADD, a 32-bit MUL, and the sign branches of main() (first /
-    second / both operands negative: (-A)+B as B-A, A-(-B) as A+B at 64 bits, -(A+B) at 128 bits, (-A)-(-B) as B-A), a 256-bit ADD and a 128-bit SUB with borrows across words.  2536-byte samples, the 114 MB key file through the codec, the fast
+    second / both operands negative: (-A)+B as B-A, A-(-B) as A+B at 64 bits, -(A+B) at 128 bits, (-A)-(-B) as B-A), a 256-bit ADD, a 128-bit SUB with borrows across words, a 64-bit MUL with a negative operand, and compute() followed by
+    compute_final() ((a + b) - c through answer.data -> cloud.data).  2536-byte samples, the 114 MB key file through the codec, the fast
     kernels behind ieache_cloud_run; the 288 value samples of answer.data equal what the oracle's orc_cloud_values made of
     the same cloud.data (tests/golden/cloud_n630.json, make_golden.py cloud_n630).  A 256-bit MUL exits 126 and leaves
     exactly the 162 304 bytes the reference's caller tests for (Cloud/dragonfly_cipher_cloud.py:1295, cloud.c:860-864)."""
@@ -678,6 +679,23 @@ def test_cloud_file_contract_at_product_parameters(ia, tmp_path):
         code, bit_size, words = tools.verif(tmp_path)
         assert bit_size == (2 * c["bits"] if c["operator"] == 4 else c["bits"])
         assert tools.verif_interpret(c["operator"], code, bit_size, words) == c["expect"], name
+    # compute() then compute_final() through the files (dragonfly_cipher_cloud.py:1219-1327): (a + b) - c, the second run's
+    # operands being the first run's answer words; value samples against the oracle's second stage
+    ch = g.get("chain")
+    if ch:
+        c1 = g["cases"][ch["first"]]
+        tools.alice(tmp_path, c1["sign_a"], c1["bits"], c1["a"], seed=c1["seed_a"])
+        tools.alice(tmp_path, c1["sign_b"], c1["bits"], c1["b"], seed=c1["seed_b"], append=True)
+        os.remove(tmp_path / "answer.data")
+        assert ia.compute(1, tmp_path, use_subprocess=True)[::2] == (0, True)
+        tools.alice(tmp_path, 0, ch["bits"], ch["c"], seed=ch["seed_c"])   # the third operand alone in cloud.data
+        rc, size, ok = ia.compute_final(ch["operator"], tmp_path, flip=True, use_subprocess=True)
+        assert (rc, ok) == (0, True) and size == 892672
+        val = tools.read_samples(tmp_path / "answer.data", p.n)[64:]
+        assert val[0].tolist() == ch["first_value_sample"] and val[-1].tolist() == ch["last_value_sample"]
+        assert digest(val) == ch["value_samples_sha256"]
+        code, bit_size, words = tools.verif(tmp_path)
+        assert bit_size == ch["bits"] and tools.verif_interpret(ch["operator"], code, bit_size, words) == ch["expect"]
     # 256-bit operands cannot be multiplied: exit code 126 and the 64 metadata samples only
     tools.alice(tmp_path, 0, 256, 5, seed=1)
     tools.alice(tmp_path, 0, 256, 7, seed=2, append=True)
