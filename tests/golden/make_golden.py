@@ -255,6 +255,8 @@ CLOUD_N630_CASES = (
     ("add256", 1, 256, (0, 0x0123456789ABCDEF0FEDCBA98765432100112233445566778899AABBCCDDEEFF, 4119),
      (0, 0x0EDCBA9876543210F0123456789ABCDEFFEEDDCCBBAA99887766554433221100, 4120)),
     ("sub128", 2, 128, (0, 0x80000000000000000000000000000001, 4121), (0, 0x00000000FFFFFFFFFFFFFFFF00000002, 4122)),   # borrows across word boundaries
+    ("sub256", 2, 256, (0, 0x8000000000000000000000000000000000000000000000000000000000000000, 4125),
+     (0, 0x0000000100000000FFFFFFFF00000001FFFFFFFE00000000FFFFFFFFFFFFFFFF, 4126)),                      # the widest SUB: borrows through all eight words
     ("mul64_second_negative", 4, 64, (0, 0xFEDCBA9876543210, 4123), (2, 0x0123456789ABCDEF, 4124)),   # split / mul32 x4 / recombination (cloud.c:220-385); ~45 min of oracle on 8 cores
 )
 CLOUD_N630_KEY_SEED, CLOUD_N630_NBIT_SEED = (314, 1592, 657), (2718, 2818)
