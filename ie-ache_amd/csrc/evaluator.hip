@@ -548,7 +548,7 @@ struct Evaluator::Impl {
     size_t ext_mux_items = 0;
     void* br_state = nullptr;  // sliced blind rotation: accumulators + rotation amounts
     size_t br_state_items = 0;
-    size_t chunk = 16384;
+    size_t chunk = 65536;         // gate instances per launch at most (scratch grows on demand, see grown())
     size_t ext_items = 0;
     Torus32* store = nullptr;
     size_t store_bytes = 0;
@@ -919,6 +919,13 @@ std::string Evaluator::kernel_for_launch(int64_t gates) const {
     return name + tag;
 }
 
+// Scratch sized by what calls have needed so far, not by the largest chunk a launch may take (65 536 gate instances are
+// ~1 GB of accumulators, extracted samples and key-switch digits): at least `need` (<= cap) items, doubling from 4 096 so
+// that a run of growing batches does not reallocate every time.
+static size_t grown(size_t have, size_t need, size_t cap) {
+    return std::max(need, std::min(std::max(cap, need), std::max<size_t>(2 * have, 4096)));
+}
+
 // Runs `items` gate instances described by W (item0 is advanced per chunk).
 static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt,
                                 Torus32* ext, int32_t steps, Torus32* dbg_acc) {
@@ -926,7 +933,8 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
         if (d->br_state_items < (size_t)cnt) {
             if (d->br_state) HIP_CHECK(hipFree(d->br_state));
             d->br_state = nullptr;
-            const size_t items = std::max<size_t>((size_t)cnt, d->chunk);
+            const size_t items = grown(d->br_state_items, (size_t)cnt, d->chunk);
+            d->br_state_items = 0;
             HIP_CHECK(hipMalloc(&d->br_state, items * w64::state_bytes_per_item(p)));
             d->br_state_items = items;
         }
@@ -981,7 +989,8 @@ static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkD
             if (d->ks_digits) HIP_CHECK(hipFree(d->ks_digits));
             d->ks_digits = nullptr;
             d->ks_digits_bytes = 0;
-            const size_t want = std::max(need, ksm::digit_scratch_bytes(d->p, (int64_t)d->chunk));
+            const size_t want = std::max(need, std::min(ksm::digit_scratch_bytes(d->p, (int64_t)d->chunk),
+                                                        std::max<size_t>(2 * d->ks_digits_bytes, ksm::digit_scratch_bytes(d->p, 4096))));
             HIP_CHECK(hipMalloc(&d->ks_digits, want));
             d->ks_digits_bytes = want;
         }
@@ -1017,14 +1026,40 @@ static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkD
     }
 }
 
+// Before an evaluation starts: scratch for its widest launch in one go (the per-launch checks below then find it in place),
+// so that a circuit whose levels widen does not reallocate -- and synchronise -- between them.
+static void reserve_scratch(const Params& p, Evaluator::Impl* d, int64_t widest_items) {
+    const size_t need = std::min<size_t>(d->chunk, (size_t)std::max<int64_t>(widest_items, 1));
+    if (d->ext_items < need) {
+        const size_t n = grown(d->ext_items, need, d->chunk);
+        if (d->ext) HIP_CHECK(hipFree(d->ext));
+        d->ext = nullptr;
+        d->ext_items = 0;
+        HIP_CHECK(hipMalloc(&d->ext, n * (size_t)(d->K.N + 4) * 4));
+        d->ext_items = n;
+    }
+    if (d->use_w64 && d->br_state_items < need) {
+        const size_t n = grown(d->br_state_items, need, d->chunk);
+        if (d->br_state) HIP_CHECK(hipFree(d->br_state));
+        d->br_state = nullptr;
+        d->br_state_items = 0;
+        HIP_CHECK(hipMalloc(&d->br_state, n * w64::state_bytes_per_item(p)));
+        d->br_state_items = n;
+    }
+}
+
 static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, WorkDesc W, int64_t items,
                       Timer& tbr, Timer& tks, EvalStats* stats) {
     const DevKeys& K = d->K;
     const size_t chunk = d->chunk;
-    if (d->ext_items < chunk) {
+    const size_t ext_need = std::min<size_t>(chunk, (size_t)std::max<int64_t>(items, 1));
+    if (d->ext_items < ext_need) {
+        const size_t n = grown(d->ext_items, ext_need, chunk);
         if (d->ext) HIP_CHECK(hipFree(d->ext));
-        HIP_CHECK(hipMalloc(&d->ext, chunk * (size_t)(K.N + 4) * 4));
-        d->ext_items = chunk;
+        d->ext = nullptr;
+        d->ext_items = 0;
+        HIP_CHECK(hipMalloc(&d->ext, n * (size_t)(K.N + 4) * 4));
+        d->ext_items = n;
     }
     for (int64_t done = 0; done < items; done += (int64_t)chunk) {
         const int64_t cnt = std::min<int64_t>((int64_t)chunk, items - done);
@@ -1179,19 +1214,22 @@ void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32*
     d_->force_generic_ks = force_generic_;
     const DevKeys& K = d_->K;
     const size_t chunk = std::max<size_t>(d_->chunk & ~(size_t)1, 2), gates_per_chunk = chunk / 2;
-    if (d_->ext_items < chunk) {
+    const size_t mux_need = std::min(gates_per_chunk, count);  // two extracted samples per MUX gate
+    if (d_->ext_items < 2 * mux_need) {
+        const size_t n = grown(d_->ext_items, 2 * mux_need, chunk);
         if (d_->ext) HIP_CHECK(hipFree(d_->ext));
         d_->ext = nullptr;
         d_->ext_items = 0;
-        HIP_CHECK(hipMalloc(&d_->ext, chunk * (size_t)(K.N + 4) * 4));
-        d_->ext_items = chunk;
+        HIP_CHECK(hipMalloc(&d_->ext, n * (size_t)(K.N + 4) * 4));
+        d_->ext_items = n;
     }
-    if (d_->ext_mux_items < gates_per_chunk) {
+    if (d_->ext_mux_items < mux_need) {
+        const size_t n = grown(d_->ext_mux_items, mux_need, gates_per_chunk);
         if (d_->ext_mux) HIP_CHECK(hipFree(d_->ext_mux));
         d_->ext_mux = nullptr;
         d_->ext_mux_items = 0;
-        HIP_CHECK(hipMalloc(&d_->ext_mux, gates_per_chunk * (size_t)(K.N + 4) * 4));
-        d_->ext_mux_items = gates_per_chunk;
+        HIP_CHECK(hipMalloc(&d_->ext_mux, n * (size_t)(K.N + 4) * 4));
+        d_->ext_mux_items = n;
     }
     Timer tall(stats != nullptr, stream_), tbr(stats != nullptr, stream_), tks(stats != nullptr, stream_);
     tall.mark();
@@ -1262,6 +1300,12 @@ void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const T
         HIP_CHECK(hipMemcpyAsync(d_->d_gates, c.gates.data(), c.gates.size() * sizeof(DevGate), hipMemcpyHostToDevice, stream_));
     HIP_CHECK(hipMemcpyAsync(d_->d_outs, c.outputs.data(), c.outputs.size() * sizeof(OutRef), hipMemcpyHostToDevice, stream_));
 
+    {
+        int64_t widest = 1;
+        for (int32_t L = 1; L <= c.n_levels(); L++)
+            widest = std::max<int64_t>(widest, (int64_t)(c.level_offset[L] - c.level_offset[L - 1]) * (int64_t)batch);
+        reserve_scratch(p_, d_, widest);
+    }
     Timer tall(stats != nullptr, stream_), tbr(stats != nullptr, stream_), tks(stats != nullptr, stream_);
     tall.mark();
     // inputs -> slots 0..n_inputs-1 of every expression

@@ -258,6 +258,7 @@ CLOUD_N630_CASES = (
     ("sub256", 2, 256, (0, 0x8000000000000000000000000000000000000000000000000000000000000000, 4125),
      (0, 0x0000000100000000FFFFFFFF00000001FFFFFFFE00000000FFFFFFFFFFFFFFFF, 4126)),                      # the widest SUB: borrows through all eight words
     ("mul64_second_negative", 4, 64, (0, 0xFEDCBA9876543210, 4123), (2, 0x0123456789ABCDEF, 4124)),   # split / mul32 x4 / recombination (cloud.c:220-385); ~45 min of oracle on 8 cores
+    ("mul128_both_negative", 4, 128, (2, 0xF0E1D2C3B4A5968778695A4B3C2D1E0F, 4127), (2, 0x0123456789ABCDEFFEDCBA9876543210, 4128)),  # cloud.c:387-647; ~2.5 h of oracle on 8 cores
 )
 CLOUD_N630_KEY_SEED, CLOUD_N630_NBIT_SEED = (314, 1592, 657), (2718, 2818)
 
