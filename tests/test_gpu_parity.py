@@ -639,7 +639,7 @@ def test_cloud_file_contract_at_product_parameters(ia, tmp_path):
     """The ./cloud process contract at n=630 (cloud.c:650-917), through the `cloud` EXECUTABLE: keygen from the documented
     seeds, `alice` twice, operator.txt, ./cloud in that directory, `verif` -- BASELINE configs[0] (16-bit a+b, zero-extended in
     the 32-bit word), 32-bit SUBs (a > b and a < b), a 64-bit ADD, a 32-bit MUL, and the sign branches of main() (first /
-    second / both operands negative: (-A)+B as B-A, A-(-B) as A+B at 64 bits, -(A+B) at 128 bits, (-A)-(-B) as B-A), a 256-bit ADD, a 128-bit SUB with borrows across words, a 64-bit MUL with a negative operand, and compute() followed by
+    second / both operands negative: (-A)+B as B-A, A-(-B) as A+B at 64 bits, -(A+B) at 128 bits, (-A)-(-B) as B-A), a 256-bit ADD, a 128-bit SUB with borrows across words, 64- and 128-bit MULs with negative operands, and compute() followed by
     compute_final() ((a + b) - c through answer.data -> cloud.data).  2536-byte samples, the 114 MB key file through the codec, the fast
     kernels behind ieache_cloud_run; the 288 value samples of answer.data equal what the oracle's orc_cloud_values made of
     the same cloud.data (tests/golden/cloud_n630.json, make_golden.py cloud_n630).  A 256-bit MUL exits 126 and leaves
