@@ -76,6 +76,7 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //     49 k_blind_rotate_w1b with s_memtime phase stamps on stderr (diagnostic)
 int32_t default_variant();
 constexpr int32_t kVariantWide = 7;
+constexpr int32_t kVariantExactOneWave = 9;  // k_blind_rotate_x1 (round 4): two limbs, one wave per gate
 constexpr int32_t kVariantOneLimb = 13;
 constexpr int32_t kVariantOneLimbDefault = 31;  // k_blind_rotate_w1b, guard on one coefficient in four (round 3)
 constexpr int32_t kVariantOneLimbTwoWaves = 36;     // k_blind_rotate_w2r (round 3; round 2's k_blind_rotate_w2s = 20)

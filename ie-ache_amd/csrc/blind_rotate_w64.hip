@@ -295,7 +295,9 @@ struct NoHook {
 // request data the caller needs right after the transform
 // POST: called once the reads of the last (lane-low) transpose are issued and before their data is used: work that does not
 // depend on them runs under that LDS round trip
-template <bool WSYNC, int XLANE = 0, int ILV = 0, class MID = NoHook, bool MID_LATE = false, int SW3 = 1, class POST = NoHook, class ROOTS = LaneRoots>
+// TBF: keep the second twiddle set's loads behind the first set's multiplies (a scheduling fence): the compiler otherwise
+// hoists them, and a caller that holds 128 registers of spectrum sums (k_blind_rotate_x1) cannot afford both sets live at once
+template <bool WSYNC, int XLANE = 0, int ILV = 0, class MID = NoHook, bool MID_LATE = false, int SW3 = 1, class POST = NoHook, class ROOTS = LaneRoots, bool TBF = false>
 __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const ROOTS& R, MID mid = MID(), POST post = POST()) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo;   // (m, l) = (lane>>3, lane&7) inside a row-block h
@@ -343,6 +345,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
         mid();
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (TBF) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 1; k < 8; k++) tB[k] = R.b(k);
     if (XLANE & 1) {
@@ -1222,6 +1225,193 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
             if (bits > __builtin_nontemporal_load(&guard[1])) atomicMax(&guard[1], bits);
             if (m > kGuardLimit) atomicAdd(&guard[0], 1u);
         }
+    }
+    if (ext) {
+        Torus32* u = ext + (size_t)item * (kN + 4);
+        for (int32_t j = lane; j <= kN; j += 64)
+            u[j] = j == 0 ? acc[0] : (j == kN ? acc[kN] : (int32_t)(0u - (uint32_t)acc[kN - j]));
+    } else {
+        const int4* src = reinterpret_cast<const int4*>(acc);
+        int4* dst = reinterpret_cast<int4*>(gacc);
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[64 * r + lane] = src[64 * r + lane];
+    }
+}
+
+// ---- K3 (+K4), throughput form of the PROVABLY EXACT product, round 4: one wave per gate on the TWO-limb spectrum ----
+// k_blind_rotate_w2 (above) gives the two-limb product -- BK split into balanced 16-bit limbs, every rounded sum below 2^35
+// of the 2^53 an FP64 mantissa holds, so rounding recovers the integer whatever the transform's schedule -- to two waves
+// per gate that exchange every forward spectrum through LDS: six workgroup barriers per CMux step.  This is that product on
+// k_blind_rotate_w1b's mapping: ONE wave owns a gate, four gates share a workgroup for the twiddle table only, no barrier
+// and nothing crossing waves inside a step, BK through buffer loads with the block index in the scalar offset, accumulators
+// first in LDS on 4 KiB boundaries (rotation address = one v_and_or of a per-step lane value), ds_add_u32 update.
+// Per step and gate: 2L forward transforms (the digits, as in the one-limb kernels), 4 x 2L row products into FOUR
+// spectrum sums s[2 c + limb] (128 VGPRs), four inverse transforms (two interleaved pairs through the gate's one tile),
+// the two limbs of an output recombined as lo + (hi << 16) mod 2^32.  With the sums taking half the register file, only two
+// BK blocks are in flight at a time: block 0 of a row is requested inside its forward transform (once the second twiddle
+// set is consumed), block q + 2 when block q has been multiplied.  No guard: nothing here can round wrongly.
+// dynamic LDS as k_blind_rotate_w1b: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2   (78 848 B -> 2 per CU)
+template <int L, int BGBIT, int BKMODE = 0>
+__global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K, const double2* __restrict__ bkf,
+                                                                      const uint16_t* __restrict__ st_bara, int32_t nb,
+                                                                      int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
+                                                                      Torus32* ext, const double2* __restrict__ gtw) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int32_t* acc_all = reinterpret_cast<int32_t*>(smem);
+    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)kW1Gates * 2 * kN * 4);
+    double2* sTw = sT_all + kW1Gates * kTile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2* sT = sT_all + wave * kTile;
+    int32_t* acc = acc_all + wave * 2 * kN;
+    const int64_t item = (int64_t)blockIdx.x * kW1Gates + wave;
+    load_twiddles(sTw, gtw, tid, 64 * kW1Gates);
+    __syncthreads();  // the only workgroup barrier
+    if (item >= items) return;
+    const LaneRoots R = make_roots(sTw, lane);
+    const uint16_t* __restrict__ bara = st_bara + (size_t)item * nb;
+    int32_t* gacc = st_acc + (size_t)item * 2 * kN;
+    {
+        const int4* src = reinterpret_cast<const int4*>(gacc);
+        int4* dst = reinterpret_cast<int4*>(acc);
+#pragma unroll
+        for (int r = 0; r < 8; r++) dst[64 * r + lane] = src[64 * r + lane];
+    }
+    wave_sync();
+
+    constexpr uint32_t halfBg = 1u << (BGBIT - 1);
+    uint32_t dec_offset = 0;
+#pragma unroll
+    for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
+    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
+    constexpr int kBlockBytes = kM * (int)sizeof(double2), kRowBytes = 4 * kBlockBytes, kStepBytes = 2 * L * kRowBytes;
+    const __amdgpu_buffer_rsrc_t bk_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(bkf), (short)0, K.n * kStepBytes, 0x00020000);
+    const int lane16 = lane * (int)sizeof(double2);
+    const unsigned char* accb = reinterpret_cast<const unsigned char*>(acc_all);  // LDS offset 0 of the workgroup
+    const uint32_t pb0 = (uint32_t)wave * (2 * kN * 4);                            // this gate's polynomial 0; polynomial 1 at + 4096
+
+    const int32_t my_a = (i0 + lane < i1) ? (int32_t)bara[i0 + lane] : 0;
+#pragma unroll 1
+    for (int32_t i = i0; i < i1; i++) {
+        const int32_t a = __builtin_amdgcn_readlane(my_a, i - i0);
+        if (a == 0) continue;  // wave-uniform; exact arithmetic makes the step a no-op
+        const int bki = i * kStepBytes;  // BK_i rows [2L][q = 2 c + limb][8][64] double2
+        double2 s[4][8];
+        uint32_t v0[8], v1[8];
+        // byte offset of coefficient (lane - a) in the 2N-ring [acc, -acc]: bits 2..11 address, bit 12 = negate
+        const uint32_t jb4 = ((uint32_t)(lane - a) & (2 * kN - 1)) << 2;
+        auto decompose = [&](const uint32_t pb, const uint32_t jb) {
+            const int32_t* accp = reinterpret_cast<const int32_t*>(accb + pb);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t t = jb + 256u * r;
+                const uint32_t o0 = (t & 4092u) | pb, o1 = o0 ^ 2048u;
+                const int32_t m0 = __builtin_amdgcn_sbfe((int32_t)t, 12, 1), m1 = __builtin_amdgcn_sbfe((int32_t)(t + 2048u), 12, 1);
+                const uint32_t rv0 = *reinterpret_cast<const uint32_t*>(accb + o0), rv1 = *reinterpret_cast<const uint32_t*>(accb + o1);
+                const uint32_t pv0 = (uint32_t)accp[64 * r + lane], pv1 = (uint32_t)accp[64 * r + lane + kM];
+                v0[r] = ((rv0 ^ (uint32_t)m0) + ((dec_offset - pv0) - (uint32_t)m0)) ^ dec_offset;
+                v1[r] = ((rv1 ^ (uint32_t)m1) + ((dec_offset - pv1) - (uint32_t)m1)) ^ dec_offset;
+            }
+        };
+        auto mac = [&](double2 (&acc_s)[8], const double2 (&x)[8], const double2 (&b)[8], auto first) {
+            constexpr bool FIRST = decltype(first)::value;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                acc_s[k] = FIRST ? cmulx<false>(x[k], b[k])
+                                 : make_double2(fma(x[k].x, b[k].x, fma(-x[k].y, b[k].y, acc_s[k].x)),
+                                                fma(x[k].x, b[k].y, fma(x[k].y, b[k].x, acc_s[k].y)));
+        };
+        auto digit_row = [&](const int sh, const int brow, auto first) {
+            double2 x[8], bA[8], bB[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
+                const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
+                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
+                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto req = [&]() { load_bk_block<true>(bA, bk_rsrc, lane16, brow); };  // block 0: output 0, low limb
+            if (BKMODE == 1) {
+                req();
+                __builtin_amdgcn_sched_barrier(0);
+                fft512_forward<true, 1, 0, NoHook, false, 1, NoHook, LaneRoots, true>(x, sT, lane, R);
+            } else {
+                fft512_forward<true, 1, 0, decltype(req), true, 1, NoHook, LaneRoots, true>(x, sT, lane, R, req);
+            }
+            load_bk_block<true>(bB, bk_rsrc, lane16, brow + kBlockBytes);          // block 1: output 0, high limb
+            __builtin_amdgcn_sched_barrier(0);
+            if (BKMODE == 2) {  // block granularity: block q + 2 requested when block q has been multiplied (A/B partner)
+                mac(s[0], x, bA, first);
+                __builtin_amdgcn_sched_barrier(0);
+                load_bk_block<true>(bA, bk_rsrc, lane16, brow + 2 * kBlockBytes);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(s[1], x, bB, first);
+                __builtin_amdgcn_sched_barrier(0);
+                load_bk_block<true>(bB, bk_rsrc, lane16, brow + 3 * kBlockBytes);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(s[2], x, bA, first);
+                mac(s[3], x, bB, first);
+            } else {
+                // register granularity: each 16-byte register of block q is re-requested for block q + 2 right behind the
+                // products that consumed it, so a request always has two blocks' worth of products (64 FMAs) to arrive under
+                constexpr bool FIRST = decltype(first)::value;
+#define IEACHE_X1_MAC2(S, B, NEXT, NEXT_OFF)                                                                              \
+    _Pragma("unroll") for (int k = 0; k < 8; k += 2) {                                                                  \
+        _Pragma("unroll") for (int kk = k; kk < k + 2; kk++)                                                            \
+            S[kk] = FIRST ? cmulx<false>(x[kk], B[kk])                                                                  \
+                          : make_double2(fma(x[kk].x, B[kk].x, fma(-x[kk].y, B[kk].y, S[kk].x)),                        \
+                                         fma(x[kk].x, B[kk].y, fma(x[kk].y, B[kk].x, S[kk].y)));                        \
+        if (NEXT) {                                                                                                     \
+            _Pragma("unroll") for (int kk = k; kk < k + 2; kk++) {                                                      \
+                const v4i_t d = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + (kk & 3) * 1024, (NEXT_OFF) + (kk >> 2) * 4096, 0); \
+                B[kk] = make_double2(__hiloint2double(d.y, d.x), __hiloint2double(d.w, d.z));                           \
+            }                                                                                                           \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }
+                IEACHE_X1_MAC2(s[0], bA, true, brow + 2 * kBlockBytes)
+                IEACHE_X1_MAC2(s[1], bB, true, brow + 3 * kBlockBytes)
+                IEACHE_X1_MAC2(s[2], bA, false, 0)
+                IEACHE_X1_MAC2(s[3], bB, false, 0)
+#undef IEACHE_X1_MAC2
+            }
+        };
+        decompose(pb0, jb4);
+        digit_row(32 - BGBIT, bki, std::true_type{});
+#pragma unroll 1
+        for (int row = 1; row < L; row++) digit_row(32 - (row + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
+        // opaque copy: the addresses and sign masks of the second decomposition are recomputed (~50 integer instructions) rather
+        // than kept from the first one across three digit rows -- 46 registers this kernel does not have (they were spilled)
+        uint32_t jb4b = jb4;
+        asm volatile("" : "+v"(jb4b));
+        decompose(pb0 + 4096u, jb4b);
+#pragma unroll 1
+        for (int row = L; row < 2 * L; row++) digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
+        // back to coefficients: s[2 c] / s[2 c + 1] hold the low / high limb sums of output polynomial c
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            fft512_inverse_pair<true>(s[2 * c], s[2 * c + 1], sT, lane, R);
+            uint32_t* accc = reinterpret_cast<uint32_t*>(acc) + c * kN;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                double l0, l1, h0, h1;
+                if (r == 0) {
+                    l0 = fma(s[2 * c][0].x, 1.0 / 512.0, kMagic), l1 = fma(s[2 * c][0].y, 1.0 / 512.0, kMagic);
+                    h0 = fma(s[2 * c + 1][0].x, 1.0 / 512.0, kMagic), h1 = fma(s[2 * c + 1][0].y, 1.0 / 512.0, kMagic);
+                } else {
+                    const double2 zl = cmulx<true>(s[2 * c][r], untwist_reg(r)), zh = cmulx<true>(s[2 * c + 1][r], untwist_reg(r));
+                    l0 = zl.x + kMagic, l1 = zl.y + kMagic, h0 = zh.x + kMagic, h1 = zh.y + kMagic;
+                }
+                const int32_t j = 64 * r + lane;
+                const uint32_t d0 = (uint32_t)__double2loint(l0) + ((uint32_t)__double2loint(h0) << 16);
+                const uint32_t d1 = (uint32_t)__double2loint(l1) + ((uint32_t)__double2loint(h1) << 16);
+                __hip_atomic_fetch_add(&accc[j], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&accc[j + kM], d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        wave_sync();
     }
     if (ext) {
         Torus32* u = ext + (size_t)item * (kN + 4);
@@ -2417,6 +2607,12 @@ void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1
     hipLaunchKernelGGL(k_bk_to_spectrum_w64_1, dim3((unsigned)npoly), dim3(64), 0, stream, d_bk_raw, d_bkf1);
 }
 
+static int32_t device_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+
 // diagnostic build (IEACHE_BR_VARIANT=1): per-segment s_memtime sums, printed per launch() call
 static unsigned long long* diag_buf() {
     static unsigned long long* p = nullptr;
@@ -2469,16 +2665,23 @@ static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream
             hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, true>), grid, dim3(128 * L), lds_wide, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw, (unsigned*)nullptr);
         return;
     }
+    if (variant == kVariantExactOneWave || variant == kVariantExactOneWave + 1) {  // round 4: one wave per gate on the two-limb spectrum
+        const int64_t items = (int64_t)grid.x;
+        const dim3 g1((unsigned)((items + kW1Gates - 1) / kW1Gates)), b1(64 * kW1Gates);
+#define IEACHE_X1(MODE)                                                                                                         \
+    {                                                                                                                           \
+        static const bool attr_set = hipFuncSetAttribute((const void*)k_blind_rotate_x1<L, BGBIT, MODE>,                        \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_w1()) == hipSuccess; \
+        if (!attr_set) throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for k_blind_rotate_x1"); \
+        hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT, MODE>), g1, b1, lds_bytes_w1(), stream, K, d_bkf, st_bara, nb, st_acc, items, \
+                           i0, i1, e, gtw);                                                                                     \
+    }
+        if (variant == kVariantExactOneWave) IEACHE_X1(0) else IEACHE_X1(2)  // + 1: BK blocks re-requested at block granularity (A/B partner)
+#undef IEACHE_X1
+        return;
+    }
     switch (variant) {
-        case 1: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw); break;
-        case 2: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, false>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
-        case 3: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
-        case 4: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, true, true, 3>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, diag_buf(), gtw); break;
-        case 5: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
-        case 11: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 0, 0, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
         case 12: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;  // every transpose through LDS (round 1's default)
-        case 10: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 0, 1>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
-        case 6: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 2>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
         // default since round 2: the forward transforms' first (lane-high) transpose cross-lane, everything else through LDS
         default: hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, false, true, 1, 0, false, true>), grid, blk, lds, stream, K, d_bkf, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw); break;
     }
@@ -2488,9 +2691,7 @@ static void launch_slice(int variant, dim3 grid, dim3 blk, size_t lds, hipStream
 static int32_t w4r_flip_period() {
     static const int32_t v = [] {
         if (const char* e = getenv("IEACHE_W4R_FLIP")) return atoi(e) > 0 ? atoi(e) : 1 << 30;
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus > 0 ? cus : 256;
+        return device_cus();
     }();
     return v;
 }

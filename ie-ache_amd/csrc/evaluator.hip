@@ -532,6 +532,7 @@ struct Evaluator::Impl {
     // "fft_audit" = K: every K-th (level, chunk) launch that took a one-limb kernel has a sample of kAuditGates of its gate
     // instances run again on the two-limb kernel and compared word for word (fft_guard[2] counts differing rows); 0 = off
     int32_t fft_audit = 64;
+    int64_t exact_one_wave_min = 1025;  // two-limb launches from this size on take k_blind_rotate_x1 (one wave per gate)
     int64_t audit_seq = 0;       // one-limb (level, chunk) launches so far
     int64_t audits = 0, audit_gates = 0, audit_mismatches = 0;
     bool audit_inject = false;   // test hook: the next audit reports a mismatch
@@ -616,10 +617,9 @@ void Evaluator::init() {
         if (const char* e = getenv("IEACHE_FFT_AUDIT")) d_->fft_audit = atoi(e) > 0 ? atoi(e) : 0;
         if (!w64::one_limb_supported(p)) d_->exact_fft = true;
         resident_two_wave_ = 4 * cus;
-        if (d_->exact_fft) {
-            resident_gates_ = 4 * cus;
-            resident_two_wave_ = 0;
-        }
+        d_->exact_one_wave_min = 4 * cus + 1;  // two-limb launches that do not fit the two-waves-per-gate kernel's 4 gates per CU
+        if (const char* e = getenv("IEACHE_EXACT_ONE_WAVE_MIN")) d_->exact_one_wave_min = atoll(e);
+        if (d_->exact_fft) resident_two_wave_ = 0;  // k_blind_rotate_x1 holds 8 gates per CU, as k_blind_rotate_w1b does
     }
     d_->p = p;
     DevKeys& K = d_->K;
@@ -749,10 +749,11 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_variant = (int32_t)value;
     } else if (name == "exact_fft" && (value == 1 || (value == 0 && w64::one_limb_supported(p_)))) {
         d_->exact_fft = value != 0;
-        resident_gates_ = (d_->exact_fft ? 4 : 8) * d_->cus;
         resident_two_wave_ = d_->exact_fft ? 0 : 4 * d_->cus;
     } else if (name == "one_limb_min" && value >= 0) {
         d_->one_limb_min = value;
+    } else if (name == "exact_one_wave_min" && value >= 0) {
+        d_->exact_one_wave_min = value;
     } else if (name == "two_wave_max" && value >= 0) {
         d_->two_wave_max = value;
     } else if (name == "four_wave_max" && value >= 0) {
@@ -893,8 +894,12 @@ static void pick_br_variant(const Params& p, const Evaluator::Impl* d, int64_t c
                 slice = variant == w64::kVariantOneLimbFourWaves ? w64::bara_stride(p)
                         : (variant == w64::kVariantOneLimbTwoWaves || cnt <= 8 * (int64_t)d->cus) ? 64 : slice;
         }
+        else if (cnt >= d->exact_one_wave_min) {
+            variant = w64::kVariantExactOneWave;  // "exact_fft" / a repeat: the two-limb product, one wave per gate
+            if (slice <= 0 && cnt <= 8 * (int64_t)d->cus) slice = 64;  // a single round of resident gates: as above
+        }
     } else if (d->exact_once && variant >= w64::kVariantOneLimb) {
-        variant = 0;
+        variant = cnt >= d->exact_one_wave_min ? w64::kVariantExactOneWave : 0;
     }
     *variant_out = variant;
     *slice_out = slice;
@@ -913,6 +918,7 @@ std::string Evaluator::kernel_for_launch(int64_t gates) const {
         case w64::kVariantOneLimbFourWaves: name = "k_blind_rotate_w4r"; break;
         case w64::kVariantWideHandoverOneLimb: name = "k_blind_rotate_wide4"; break;
         case w64::kVariantWide: name = "k_blind_rotate_wide"; break;
+        case w64::kVariantExactOneWave: name = "k_blind_rotate_x1"; break;
         case 0: name = "k_blind_rotate_w2"; break;
         default: snprintf(tag, sizeof tag, "<%d,%d> br_variant %d", (int)p_.l, (int)p_.Bgbit, (int)variant); name = "k_blind_rotate"; break;
     }

@@ -733,9 +733,14 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         ctx.set_option("br_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref), sl
     ctx.set_option("br_slice", 0)
-    for variant in (2, 3, 5, 6, 10, 11, 12):                   # workgroup-barrier sync; cross-lane (DPP/permlane) transposes: both /
-        ctx.set_option("br_variant", variant)              # lane-high only / lane-low only; stores interleaved with multiplies
-        assert np.array_equal(ctx.gates(ia.GATE_AND, a[:300], b[:300]), ref[:300]), variant
+    for variant in (9, 10, 12):                            # two limbs: one wave per gate (BK re-requested per register / per block);
+        ctx.set_option("br_variant", variant)              # two waves per gate with every transpose through LDS
+        assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), variant   # ragged last workgroup of 4 gates
+    ctx.set_option("br_variant", 9)
+    for sl in (1, 5, 64):
+        ctx.set_option("br_slice", sl)
+        assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), sl
+    ctx.set_option("br_slice", 0)
     ctx.set_option("br_variant", 7)                        # 2L-waves-per-gate (latency) kernel, forced for every launch size
     for sl in (16, 5, 4096):                               # sliced, ragged, whole rotation in one launch
         ctx.set_option("br_slice", sl)
@@ -1027,7 +1032,7 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
     assert names[0] == "k_blind_rotate_wide4" and names[3] == "k_blind_rotate_w1b" and len(set(names)) == 4, names
     assert ctx.kernel_for_launch(900).endswith("<3,7>")
     ctx.set_option("exact_fft", 1)
-    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (200, cnt)] == ["k_blind_rotate_wide", "k_blind_rotate_w2"]
+    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (200, 900, cnt)] == ["k_blind_rotate_wide", "k_blind_rotate_w2", "k_blind_rotate_x1"]
     ctx.set_option("exact_fft", 0)
     mid = ctx.gates(ia.GATE_XOR, a[:900], b[:900])
     assert np.array_equal(mid, results[1][0][:900])
