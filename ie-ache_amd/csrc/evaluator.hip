@@ -745,7 +745,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 0 && value <= 4096) {  // 0 = by kernel and launch size
         d_->br_slice = (int32_t)value;
-    } else if (name == "br_variant" && value >= 0 && value <= 60) {
+    } else if (name == "br_variant" && value >= 0 && value <= 1000 && w64::variant_known((int32_t)value)) {
         d_->br_variant = (int32_t)value;
     } else if (name == "exact_fft" && (value == 1 || (value == 0 && w64::one_limb_supported(p_)))) {
         d_->exact_fft = value != 0;
@@ -898,7 +898,7 @@ static void pick_br_variant(const Params& p, const Evaluator::Impl* d, int64_t c
             variant = w64::kVariantExactOneWave;  // "exact_fft" / a repeat: the two-limb product, one wave per gate
             if (slice <= 0 && cnt <= 8 * (int64_t)d->cus) slice = 64;  // a single round of resident gates: as above
         }
-    } else if (d->exact_once && variant >= w64::kVariantOneLimb) {
+    } else if (d->exact_once && w64::variant_one_limb(variant)) {
         variant = cnt >= d->exact_one_wave_min ? w64::kVariantExactOneWave : 0;
     }
     *variant_out = variant;
@@ -966,7 +966,7 @@ static void maybe_audit(const Params& p, Evaluator::Impl* d, hipStream_t stream,
     if (!d->use_w64 || d->fft_audit <= 0 || !d->fft_guard) return;
     int32_t variant, slice;
     pick_br_variant(p, d, cnt, &variant, &slice);
-    if (variant < w64::kVariantOneLimb) return;  // the launch was exact by construction
+    if (!w64::variant_one_limb(variant)) return;  // the launch was exact by construction
     if (++d->audit_seq % d->fft_audit != 0) return;
     const int64_t m = std::min<int64_t>(kAuditGates, cnt);
     const int64_t off = cnt > m ? (int64_t)(((uint64_t)d->audit_seq * 0x9E3779B97F4A7C15ull >> 33) % (uint64_t)(cnt - m + 1)) : 0;

@@ -11,4 +11,4 @@ D=build/alt_$NAME; mkdir -p $D
     -c blind_rotate_w64.hip -o $D/blind_rotate_w64.o 2> $D/remarks.txt
 OBJS=$(ls build/*.o | grep -v blind_rotate_w64.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fopenmp -o $D/libieache.so $OBJS $D/blind_rotate_w64.o
-grep -A 12 "Function Name: .*18k_blind_rotate_w1bILi3ELi7ELi2ELi0ELi0ELb0ELb0E" $D/remarks.txt | grep -E "VGPRs:|VGPRs Spill|ScratchSize" | sed 's/.*remark: //' | tr '\n' ' '; echo " <- k_blind_rotate_w1b<3,7,2> in $D"
+grep -A 12 "Function Name: .*18k_blind_rotate_w1bILi3ELi7ELi2ELb0E" $D/remarks.txt | grep -E "VGPRs:|VGPRs Spill|ScratchSize" | sed 's/.*remark: //' | tr '\n' ' '; echo " <- k_blind_rotate_w1b<3,7,2> in $D"
