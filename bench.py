@@ -38,13 +38,14 @@ LANES, FLOP_PER_INST = 64, 2          # one wave-instruction = 64 lanes; an FMA 
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # wave-instructions/s the chip can issue: 256 CUs x 4 SIMDs, one per 4 cycles at 2.4 GHz
 
 
-def algorithmic_flops_per_gate(p):
+def algorithmic_flops_per_gate(p, limbs=1):
     """per CMux step (k+1)l forward + (k+1) inverse negacyclic transforms of N/2 complex points
     (5 M log2 M flop each) + (k+1)^2 l M complex multiply-accumulates (8 flop each); times n steps.
-    n=630, N=1024, k=1, l=3: 233 472 flop per step, 1.47e8 per gate."""
+    n=630, N=1024, k=1, l=3: 233 472 flop per step, 1.47e8 per gate.  limbs=2 (the provably exact product: BK in two
+    16-bit limbs): the forward transforms are shared, inverse transforms and multiply-accumulates double -- 328 704 per step."""
     M = p.N // 2
     logM = M.bit_length() - 1
-    per_step = ((p.k + 1) * p.l + (p.k + 1)) * 5 * M * logM + (p.k + 1) ** 2 * p.l * M * 8
+    per_step = ((p.k + 1) * p.l + limbs * (p.k + 1)) * 5 * M * logM + limbs * (p.k + 1) ** 2 * p.l * M * 8
     return per_step * p.n
 
 
@@ -92,7 +93,7 @@ def pmc_counters(kernel_variant):
         return None
 
 
-def roofline(p, stats, gate_rate, pmc, launch_kernel=None):
+def roofline(p, stats, gate_rate, pmc, launch_kernel=None, limbs=1):
     """The record for one timed leg, for its dominant kernel (the blind rotation).
 
     bound fp64_valu: BK is shared by every gate of a launch out of L2 (hbm_model.reuse_factor), so what limits the
@@ -104,7 +105,7 @@ def roofline(p, stats, gate_rate, pmc, launch_kernel=None):
     hbm_model is SURVEY 8(d)'s streaming-model figure, priced end to end on the leg's own rate.
     launch_kernel: the kernel this leg's launch size selects (Context.kernel_for_launch); the committed PMC / rocprof
     evidence is attached only when it was collected on that kernel."""
-    bk_b, ksk_b, io_b = algorithmic_bytes(p)
+    bk_b, ksk_b, io_b = algorithmic_bytes(p)  # the streaming model counts the key as libtfhe holds it, whatever form the kernel reads
     per_gate = bk_b + ksk_b + io_b
     br_avg_ms = stats.blind_rotate_ms / max(1, stats.blind_rotate_launches)
     ks_avg_ms = stats.keyswitch_ms / max(1, stats.keyswitch_launches)
@@ -117,7 +118,7 @@ def roofline(p, stats, gate_rate, pmc, launch_kernel=None):
     if pmc and launch_kernel and (pmc.get("kernel") or "").split("<")[0] != launch_kernel.split("<")[0]:
         pmc_other, pmc = pmc, None  # counters of another kernel say nothing about this one
     traffic = pmc["hbm_bytes_per_gate_step"] * gates_per_launch * steps_per_launch if pmc else None
-    alg_flop = algorithmic_flops_per_gate(p)
+    alg_flop = algorithmic_flops_per_gate(p, limbs)
     achieved = br_gate_rate * alg_flop * 1e-12
     out = {"bound": "fp64_valu", "unit": "TFLOP/s", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
            "frac": achieved / FP64_VALU_PEAK_TFLOPS, "frac_algorithmic_flops": achieved / FP64_VALU_PEAK_TFLOPS,
@@ -129,9 +130,10 @@ def roofline(p, stats, gate_rate, pmc, launch_kernel=None):
            "rocprof_avg_launch_ms": (pmc or {}).get("rocprof_avg_launch_ms"), "rocprof_stats": (pmc or {}).get("rocprof_stats"),
            "blind_rotate_share": stats.blind_rotate_ms / max(1e-9, stats.total_ms),
            "keyswitch_share": stats.keyswitch_ms / max(1e-9, stats.total_ms),
-           "note": "achieved = SURVEY 8(d) algorithmic flops (8 transforms x 5 M log2 M + 12 M complex MACs per CMux step) of a launch / its "
+           "note": "achieved = SURVEY 8(d) algorithmic flops (%d transforms x 5 M log2 M + %d M complex MACs per CMux step) of a launch / its "
                    "HIP-event duration; 100 %% = %.0f gates/s per GPU.  rocprof_avg_launch_ms: the same kernel's average in the committed "
-                   "rocprofv3 --kernel-trace --stats summary (rocprof_stats), at the geometry named there" % (FP64_VALU_PEAK_TFLOPS * 1e12 / alg_flop)}
+                   "rocprofv3 --kernel-trace --stats summary (rocprof_stats), at the geometry named there"
+                   % ((p.k + 1) * p.l + limbs * (p.k + 1), limbs * (p.k + 1) ** 2 * p.l, FP64_VALU_PEAK_TFLOPS * 1e12 / alg_flop)}
     if pmc_other:
         out["pmc_note"] = ("launches of %.0f gates take %s; the committed counter passes (%s) were collected on %s, so no traffic / "
                            "vector-issue figures are attached to this leg" % (gates_per_launch, launch_kernel, pmc_other.get("source"), pmc_other.get("kernel")))
@@ -237,6 +239,9 @@ def cpu_baseline(p, keys, seconds=12.0):
                       "sample": "%d independent AND gates in %.1f s, OpenMP over gates on the %d CPUs this job may use "
                                 "(the host's hardware threads capped by its cgroup CPU quota), same back-end" % (count, dta, cores)},
         "real_libtfhe": ("in the loader cache but not timed: %s" % probe) if probe else "unavailable on this host (no libtfhe* in /etc/ld.so.cache = `ldconfig -p | grep tfhe` empty)",
+        "note": "a plain-C port, about half as fast as the library it restates: libtfhe documents ~13 ms per bootstrapped gate on one core "
+                "(~77 gates/s; BASELINE.md section 1) with its hand-vectorised FFT, this port measures %.1f ms -- halve any GPU/CPU "
+                "ratio read off `value`; the ratio is not a quality claim either way (roofline.frac is)" % (1e3 * dt / max(1, n)),
     }
 
 
@@ -309,6 +314,24 @@ def progress(rank, msg):
         print("[bench %6.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
+def count_gpus_without_runtime():
+    """GPUs of this node as the kernel driver lists them (KFD topology: nodes with SIMDs), narrowed by HIP_/ROCR_VISIBLE_DEVICES;
+    None when sysfs does not say (the ranks then report a shortage themselves)."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            props = dict(l.split()[:2] for l in open(os.path.join(base, node, "properties")) if len(l.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([d for d in v.split(",") if d.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves, as a child process tree
     (never exec: this must also work where a GPU-initialised process may not be replaced), relay rank 0's JSON line on
@@ -316,9 +339,8 @@ def self_launch(args):
     import socket
     import subprocess
     if args.backend == "nccl":
-        import torch  # counting devices does not initialise the GPU in this process
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        have = count_gpus_without_runtime()  # no HIP / torch call in the launcher: it must never hold a GPU context
+        if have is not None and have < args.gpus:
             print("[bench] --gpus %d but this node shows %d GPU(s); one rank per GPU is needed for RCCL "
                   "(--backend gloo rehearses the flow with ranks sharing a GPU)" % (args.gpus, have), file=sys.stderr)
             return 2
@@ -360,6 +382,8 @@ def main():
     ap.add_argument("--mul128-batch", type=int, default=128)
     ap.add_argument("--time-box", type=float, default=330.0,
                     help="a leg is skipped (and named in `skipped_legs`) when the run has already taken this many seconds minus the leg's estimate")
+    ap.add_argument("--exact-leg", default="on", choices=["on", "off"],
+                    help="after the primary leg: the same batch once more on the provably exact two-limb kernels (`exact` in the line)")
     ap.add_argument("--extras", action="store_true",
                     help="also time the two opt-in, decrypt-identical-only 32-bit multipliers (constant-folded, carry-save) in the mul32 leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -416,6 +440,38 @@ def main():
     elapsed, per_rank = timed(torch, dist, world, dev, args.backend, lambda: [step(stats) for _ in range(args.steps)])
     primary_rate = info.bootstraps * batch * args.steps * world / elapsed
     progress(rank, "%s x%d: %.0f gate ops/s" % (args.workload, batch, primary_rate))
+
+    # ---- the same batch once more on the PROVABLY EXACT product (two-limb transform, exact_fft = 1): one untimed pass, one timed
+    # pass, and its outputs compared word for word with the guarded one-limb pass above ----
+    exact_out = None
+    if args.exact_leg != "off" and "onelimb" in ctx.kernel_variant:
+        primary_out = d_out
+        d_out = torch.zeros_like(primary_out)
+        ctx.set_option("exact_fft", 1)
+        exact_kernel_variant = ctx.kernel_variant
+        step()                                            # untimed: first launches of the two-limb kernels, scratch in place
+        est = ia.Stats()
+        e_elapsed, e_per_rank = timed(torch, dist, world, dev, args.backend, lambda: step(est))
+        ctx.set_option("exact_fft", 0)
+        same = bool(torch.equal(primary_out, d_out))
+        if dist is not None:
+            t = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            same = bool(t.item() > 0.5)
+        assert same, "the guarded one-limb pass and the exact two-limb pass differ"
+        e_rate = info.bootstraps * batch * world / e_elapsed
+        progress(rank, "%s x%d on the exact (two-limb) kernels: %.0f gate ops/s, outputs identical to the one-limb pass" % (args.workload, batch, e_rate))
+        exact_out = {"what": "the primary leg's batch on the provably exact product (exact_fft = 1: BK in two balanced 16-bit limbs, every rounded "
+                             "sum < 2^35 in a 53-bit mantissa, so rounding recovers the integer whatever the transform's schedule)",
+                     "workload": config_name, "batch_per_gpu": batch, "passes": 1, "warmup_passes": 1, "ms_per_pass": e_elapsed * 1e3,
+                     "gate_ops_per_s": e_rate, "per_rank_gate_ops_per_s": [info.bootstraps * batch / t for t in e_per_rank],
+                     "kernel": exact_kernel_variant,
+                     "bit_identical_to_primary_leg": same,
+                     "checked": "all %d x %d output samples equal the one-limb pass's, word for word (torch.equal on the device buffers)" % (batch, info.n_outputs),
+                     "vs_primary": e_rate / primary_rate,
+                     "roofline": roofline(p, est, e_rate / world, pmc_counters(exact_kernel_variant),
+                                          ctx_kernel_exact(ctx, round(est.bootstraps / max(1, est.chunks))), limbs=2)}
+        del primary_out
     del d_in, d_out
 
     # ---- the other configs, one full timed pass each on the same resident key ----
@@ -445,6 +501,7 @@ def main():
             progress(rank, "%s x%d skipped: time box" % (key, lb))
             continue
         linfo, linb, ld_in, ld_out = make_inputs(ia, tools, torch, ctx, p, lwe_key, lkind, lbits, lb, rank, dev, 5000 + 1000 * len(leg_out))
+        ctx.prepare(lkind, lbits, lb)  # untimed: circuit built and levelised, wire store and the widest level's scratch allocated
         lst = ia.Stats()
         l_elapsed, l_per_rank = timed(torch, dist, world, dev, args.backend,
                                       lambda: ctx.eval_batch_device(lkind, lbits, lb, ld_in.data_ptr(), ld_out.data_ptr(), lst))
@@ -456,6 +513,9 @@ def main():
                "gate_ops_per_s": l_rate, "expressions_per_s": lb * world / l_elapsed,
                "per_rank_gate_ops_per_s": [int(linfo.bootstraps) * lb / t for t in l_per_rank],
                "checked": "all %d expressions of the timed pass decrypt to the integer result" % lb,
+               "warmup": "no warm-up pass (one is %.0f s); an untimed prepare call built the circuit and allocated the wire store and the "
+                         "widest level's scratch beforehand, so the timed pass makes no allocation; every kernel it launches has run in "
+                         "the primary leg" % l_elapsed,
                "roofline": roofline(p, lst, l_rate / world, pmc, ctx.kernel_for_launch(round(lst.bootstraps / max(1, lst.chunks))))}
         if lb != full_batch:
             rec["sub_batch_of"] = full_batch
@@ -500,6 +560,17 @@ def main():
             "fft_guard": fft_guard_record(ctx),
         }
         out.update(leg_out)
+        if exact_out:
+            out["exact"] = exact_out
+        if "mul32" in leg_out:
+            # BASELINE.json quotes its metric and target on batched 32-bit MUL: that leg, by name, at the top level.  `value` stays
+            # on the K timed steps of configs[1] because one pass of this leg is ~57 s and the driver asks for 20 steps
+            m = leg_out["mul32"]
+            out["metric_leg"] = {"workload": m["workload"], "batch_per_gpu": m["batch_per_gpu"], "gate_ops_per_s": m["gate_ops_per_s"],
+                                 "mul32_per_s": m["mul32_per_s"], "passes": m["passes"], "ms_per_pass": m["ms_per_pass"],
+                                 "roofline_frac": m["roofline"]["frac"], "details": "mul32"}
+            out["config"]["workload"] = "%s (`value`: K timed steps); %s (`metric_leg`: one full pass)" % (config_name, m["workload"])
+            out["config"]["value_workload"] = config_name
         if skipped:
             out["skipped_legs"] = skipped
         if "mul32" in leg_out:
@@ -512,6 +583,15 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def ctx_kernel_exact(ctx, gates):
+    """Context.kernel_for_launch under exact_fft = 1"""
+    ctx.set_option("exact_fft", 1)
+    try:
+        return ctx.kernel_for_launch(gates)
+    finally:
+        ctx.set_option("exact_fft", 0)
 
 
 def fft_guard_record(ctx):

@@ -110,6 +110,15 @@ const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits, size_t batch = 0
         if (it != ctx->circuits.end()) return &it->second;
         Circuit c;
         if (!build_circuit(kind, bits, &c, true, ctx->fold, cap)) return nullptr;
+        if (cap != 0) {  // bounded: one level-capped variant per (kind, width, folding) -- the cap follows the batch size
+            for (auto jt = ctx->circuits.begin(); jt != ctx->circuits.end();) {
+                const auto& k = jt->first;
+                if (std::get<0>(k) == kind && std::get<1>(k) == bits && std::get<2>(k) == ctx->fold && std::get<3>(k) != 0)
+                    jt = ctx->circuits.erase(jt);
+                else
+                    ++jt;
+            }
+        }
         return &ctx->circuits.emplace(key, std::move(c)).first->second;
     };
     const Circuit* base = fetch(0);
@@ -391,6 +400,16 @@ int ieache_eval_batch_device(ieache_ctx* ctx, int kind, int bits, size_t batch, 
         EvalStats st;
         ctx->eval->eval_circuit_device(*c, batch, d_in, d_out, stats ? &st : nullptr);
         to_stats(st, stats);
+        return 0;
+    });
+}
+
+int ieache_prepare_batch(ieache_ctx* ctx, int kind, int bits, size_t batch) {
+    return guarded([&] {
+        if (!ctx) return fail(IEACHE_EINVAL, "null argument");
+        const Circuit* c = get_circuit(ctx, kind, bits, batch);
+        if (!c) return fail(IEACHE_EINVAL, "unsupported circuit kind/bits");
+        ctx->eval->prepare_circuit(*c, batch);
         return 0;
     });
 }

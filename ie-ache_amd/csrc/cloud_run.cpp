@@ -318,23 +318,36 @@ void cloud_eval_jobs(Evaluator& eval, const std::vector<CloudJob*>& jobs, std::v
     // built circuits are kept for the life of the process (a daemon evaluates the same handful over and over; building the
     // 128-bit multiplier's DAG and levelising it takes longer than evaluating a small batch of it), keyed like capi.cpp's
     // per-context cache: (kind, width, folding, level cap)
-    static std::mutex cache_mutex;
-    static std::map<std::tuple<int32_t, int32_t, bool, int32_t>, std::unique_ptr<Circuit>> cache;
-    auto fetch = [&](int32_t cap) -> const Circuit* {
-        std::lock_guard<std::mutex> lock(cache_mutex);
-        const auto key = std::make_tuple(first.kind, first.int_bit, first.fold, cap);
-        auto it = cache.find(key);
-        if (it != cache.end()) return it->second.get();
-        std::unique_ptr<Circuit> c(new Circuit);
-        if (!build_circuit(first.kind, first.int_bit, c.get(), true, first.fold, cap)) return nullptr;
-        return cache.emplace(key, std::move(c)).first->second.get();
+    // Bounded: per (kind, width, folding) the default schedule plus ONE level-capped variant, the most recent (the cap follows
+    // the batch size, and a long-running daemon sees many batch sizes; each entry of the wide multipliers is several MB).
+    // Entries are shared_ptr: an evaluation in flight keeps its circuit alive when another thread's call replaces it.
+    struct Entry {
+        std::shared_ptr<const Circuit> base, capped;
+        int32_t cap = 0;
     };
-    const Circuit* base = fetch(0);
+    static std::mutex cache_mutex;
+    static std::map<std::tuple<int32_t, int32_t, bool>, Entry> cache;
+    auto fetch = [&](int32_t cap) -> std::shared_ptr<const Circuit> {
+        std::lock_guard<std::mutex> lock(cache_mutex);
+        Entry& e = cache[std::make_tuple(first.kind, first.int_bit, first.fold)];
+        if (cap == 0 && e.base) return e.base;
+        if (cap != 0 && e.capped && e.cap == cap) return e.capped;
+        std::shared_ptr<Circuit> c(new Circuit);
+        if (!build_circuit(first.kind, first.int_bit, c.get(), true, first.fold, cap)) return nullptr;
+        if (cap == 0) {
+            e.base = c;
+        } else {
+            e.capped = c;  // replaces the variant of another batch size
+            e.cap = cap;
+        }
+        return c;
+    };
+    const std::shared_ptr<const Circuit> base = fetch(0);
     if (!base) throw std::invalid_argument("unsupported circuit");
-    const Circuit* circ = base;
+    std::shared_ptr<const Circuit> circ = base;
     const int32_t cap = circuit_level_cap(*base, (int64_t)jobs.size(), eval.resident_gates(), eval.resident_gates_two_wave());
     if (cap > 0) {
-        const Circuit* capped = fetch(cap);
+        const std::shared_ptr<const Circuit> capped = fetch(cap);
         if (capped && capped->balanced_schedule) circ = capped;
     }
     const size_t S = (size_t)first.params.n + 1, n_in = (size_t)circ->n_inputs * S, n_out = circ->outputs.size() * S;

@@ -429,6 +429,7 @@ void decode(const std::string& path, const std::vector<Layout>& candidates, cons
     size_t size_matches = 0;
     std::string why;
     std::vector<const Layout*> passing;
+    std::vector<char> passing_d0_zero;  // per passing layout: every sampled d = 0 row of the key-switch key was all zero
     auto plausible_variance = [&](size_t at) {
         // a variance is -1 (libtfhe's "unset"), 0, or a small positive number.  Eight bytes of uniformly random key
         // material pass this with probability ~1/4 (sign bit clear and exponent below 1023), and eight ZERO bytes -- the
@@ -442,7 +443,7 @@ void decode(const std::string& path, const std::vector<Layout>& candidates, cons
     for (const Layout& L : candidates) {
         if (L.bytes(p) != bin.total) continue;
         size_matches++;
-        bool ok = true;
+        bool ok = true, d0_zero = true;
         size_t pos = 0;
         auto reject = [&](const std::string& msg) {
             if (why.empty()) why = msg;
@@ -466,11 +467,15 @@ void decode(const std::string& path, const std::vector<Layout>& candidates, cons
                 std::vector<int32_t> row((size_t)p.n + 1);
                 for (size_t ij = 0; ij < n_ij && ok; ij += stride_ij) {
                     const size_t at = pos + ij * per_ij * rec;
-                    if (!f.skip_d0) {  // KS[i][j][0] encrypts 0 without noise: an all-zero sample (lweNoiselessTrivial)
+                    if (!f.skip_d0 && d0_zero) {
+                        // libtfhe's KS[i][j][0] encrypts 0 without noise: an all-zero sample (lweNoiselessTrivial).  A SOFT
+                        // property: lweKeySwitch never reads those rows (k_ksm_prepare zeroes them whatever the file held), and a
+                        // generator that encrypts h = 0 with noise writes a perfectly usable key -- so it only breaks ties
+                        // between hypotheses that pass everything else (below), it does not reject one
                         bin.read(at, S4, row.data());
                         for (int32_t v : row)
                             if (v != 0) {
-                                reject("a d = 0 row of the key-switch key is not zero");
+                                d0_zero = false;
                                 break;
                             }
                     }
@@ -500,7 +505,21 @@ void decode(const std::string& path, const std::vector<Layout>& candidates, cons
             }
             pos += Layout::field_bytes(f, p);
         }
-        if (ok) passing.push_back(&L);
+        if (ok) {
+            passing.push_back(&L);
+            passing_d0_zero.push_back(d0_zero ? 1 : 0);
+        }
+    }
+    if (passing.size() > 1) {
+        // tie-break: hypotheses whose d = 0 rows are all zero (libtfhe's own writer) go before those where they are not
+        bool any_zero = false;
+        for (char z : passing_d0_zero) any_zero = any_zero || z;
+        if (any_zero) {
+            std::vector<const Layout*> kept;
+            for (size_t q = 0; q < passing.size(); q++)
+                if (passing_d0_zero[q]) kept.push_back(passing[q]);
+            passing.swap(kept);
+        }
     }
     if (passing.size() > 1) {
         // Two layouts of the same size both look sound: decoding the wrong one would shift the key material by a few

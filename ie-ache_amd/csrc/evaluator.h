@@ -63,6 +63,8 @@ public:
     // One circuit on `batch` independent expressions.
     //   d_in  [batch][circuit.n_inputs][lwe_stride]
     //   d_out [batch][circuit.outputs.size()][lwe_stride]
+    // allocates what an evaluation of `c` over `batch` expressions needs (idempotent; eval_circuit_device calls it itself)
+    void prepare_circuit(const Circuit& c, size_t batch);
     void eval_circuit_device(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
                              EvalStats* stats);
 

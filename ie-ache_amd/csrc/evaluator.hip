@@ -737,7 +737,8 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->ks_gates = (int32_t)value;
     } else if (name == "ks_mfma_min" && value >= 0) {
         d_->ks_mfma_min = value;
-    } else if (name == "ks_mfma_split" && value >= 0 && value <= 64) {
+    } else if (name == "ks_mfma_split" && value >= 0 && value <= 64 && (value & (value - 1)) == 0 &&
+               (value == 0 || (p_.N / 4) % value == 0)) {  // 0 = by launch size; else a power of two that divides the N/4 K-steps
         d_->ks_mfma_split = (int32_t)value;
     } else if (name == "ks_split_max" && value >= 1 && value <= 64) {
         d_->ks_split_max = (int32_t)value;
@@ -776,8 +777,8 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
 
 std::string Evaluator::kernel_variant() const {
     if (!w64::supported(p_) || force_generic_) return "generic-radix2";
-    // the kernel wide launches take: one wave per gate on the one-limb spectrum, or ("exact_fft") two waves on two limbs
-    return d_->exact_fft ? "w2x64-radix8-registers" : "w1x64-radix8-onelimb";
+    // the kernel wide launches take: one wave per gate, on the one-limb spectrum or ("exact_fft") on the two-limb one
+    return d_->exact_fft ? "x1x64-radix8-twolimb" : "w1x64-radix8-onelimb";
 }
 
 void Evaluator::load_keys_host(const Torus32* bk, const Torus32* ksk) {
@@ -984,22 +985,27 @@ static void maybe_audit(const Params& p, Evaluator::Impl* d, hipStream_t stream,
     d->audit_gates += m;
 }
 
+// digit scratch of the MFMA key switch for launches of up to `cnt` gates (doubling from 4 096 gates' worth, capped at a chunk's)
+static void reserve_ks_digits(Evaluator::Impl* d, int64_t cnt) {
+    const size_t need = ksm::digit_scratch_bytes(d->p, cnt);
+    if (d->ks_digits_bytes >= need) return;
+    const size_t have = d->ks_digits_bytes;
+    if (d->ks_digits) HIP_CHECK(hipFree(d->ks_digits));
+    d->ks_digits = nullptr;
+    d->ks_digits_bytes = 0;
+    const size_t want = std::max(need, std::min(ksm::digit_scratch_bytes(d->p, (int64_t)d->chunk),
+                                                std::max<size_t>(2 * have, ksm::digit_scratch_bytes(d->p, 4096))));
+    HIP_CHECK(hipMalloc(&d->ks_digits, want));
+    d->ks_digits_bytes = want;
+}
+
 static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt, const Torus32* ext,
                              Torus32* flat_out, bool force_generic) {
     const DevKeys& K = d->K;
     const dim3 grid((unsigned)cnt), blk(kKsThreads);
     const int nld = force_generic ? 0 : d->ks_nld;
     if (!force_generic && d->ks_mfma_ok && d->ks_limbs && cnt >= d->ks_mfma_min) {
-        const size_t need = ksm::digit_scratch_bytes(d->p, cnt);
-        if (d->ks_digits_bytes < need) {
-            if (d->ks_digits) HIP_CHECK(hipFree(d->ks_digits));
-            d->ks_digits = nullptr;
-            d->ks_digits_bytes = 0;
-            const size_t want = std::max(need, std::min(ksm::digit_scratch_bytes(d->p, (int64_t)d->chunk),
-                                                        std::max<size_t>(2 * d->ks_digits_bytes, ksm::digit_scratch_bytes(d->p, 4096))));
-            HIP_CHECK(hipMalloc(&d->ks_digits, want));
-            d->ks_digits_bytes = want;
-        }
+        reserve_ks_digits(d, cnt);
         ksm::launch(d->p, K, w, cnt, ext, flat_out, d->ks_limbs, d->ks_digits, d->ks_mfma_split, d->cus, stream);
         return;
     }
@@ -1052,6 +1058,8 @@ static void reserve_scratch(const Params& p, Evaluator::Impl* d, int64_t widest_
         HIP_CHECK(hipMalloc(&d->br_state, n * w64::state_bytes_per_item(p)));
         d->br_state_items = n;
     }
+    // the MFMA key switch's digit scratch for the widest launch that will take it
+    if (!d->force_generic_ks && d->ks_mfma_ok && d->ks_limbs && (int64_t)need >= d->ks_mfma_min) reserve_ks_digits(d, (int64_t)need);
 }
 
 static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, WorkDesc W, int64_t items,
@@ -1275,15 +1283,17 @@ void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32*
     }
 }
 
-void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
-                                         EvalStats* stats) {
+// Everything an evaluation of `c` over `batch` expressions allocates -- the wire store, the gate / output tables, the scratch
+// of its widest level (extracted samples, blind-rotation state, key-switch digits) -- so that the evaluation itself makes no
+// allocation (each one is a device-wide synchronisation).  eval_circuit_device calls it; a caller that times its first
+// evaluation calls it beforehand (ieache_prepare_batch).
+void Evaluator::prepare_circuit(const Circuit& c, size_t batch) {
     if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
     HIP_CHECK(hipSetDevice(device_));
     if (batch == 0) return;
     d_->use_w64 = w64::supported(p_) && !force_generic_;
     d_->force_generic_ks = force_generic_;
-    const int32_t stride = d_->K.stride;
-    const size_t row_bytes = (size_t)stride * 4;
+    const size_t row_bytes = (size_t)d_->K.stride * 4;
     const size_t need = batch * (size_t)c.n_slots * row_bytes;
     if (d_->store_bytes < need) {
         if (d_->store) HIP_CHECK(hipFree(d_->store));
@@ -1294,24 +1304,37 @@ void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const T
     }
     if (d_->d_gates_cap < c.gates.size()) {
         if (d_->d_gates) HIP_CHECK(hipFree(d_->d_gates));
+        d_->d_gates = nullptr;
+        d_->d_gates_cap = 0;
         HIP_CHECK(hipMalloc(&d_->d_gates, c.gates.size() * sizeof(DevGate)));
         d_->d_gates_cap = c.gates.size();
     }
     if (d_->d_outs_cap < c.outputs.size()) {
         if (d_->d_outs) HIP_CHECK(hipFree(d_->d_outs));
+        d_->d_outs = nullptr;
+        d_->d_outs_cap = 0;
         HIP_CHECK(hipMalloc(&d_->d_outs, c.outputs.size() * sizeof(OutRef)));
         d_->d_outs_cap = c.outputs.size();
     }
+    int64_t widest = 1;
+    for (int32_t L = 1; L <= c.n_levels(); L++)
+        widest = std::max<int64_t>(widest, (int64_t)(c.level_offset[L] - c.level_offset[L - 1]) * (int64_t)batch);
+    reserve_scratch(p_, d_, widest);
+}
+
+void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
+                                         EvalStats* stats) {
+    if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
+    HIP_CHECK(hipSetDevice(device_));
+    if (batch == 0) return;
+    d_->use_w64 = w64::supported(p_) && !force_generic_;
+    d_->force_generic_ks = force_generic_;
+    const int32_t stride = d_->K.stride;
+    const size_t row_bytes = (size_t)stride * 4;
+    prepare_circuit(c, batch);
     if (!c.gates.empty())
         HIP_CHECK(hipMemcpyAsync(d_->d_gates, c.gates.data(), c.gates.size() * sizeof(DevGate), hipMemcpyHostToDevice, stream_));
     HIP_CHECK(hipMemcpyAsync(d_->d_outs, c.outputs.data(), c.outputs.size() * sizeof(OutRef), hipMemcpyHostToDevice, stream_));
-
-    {
-        int64_t widest = 1;
-        for (int32_t L = 1; L <= c.n_levels(); L++)
-            widest = std::max<int64_t>(widest, (int64_t)(c.level_offset[L] - c.level_offset[L - 1]) * (int64_t)batch);
-        reserve_scratch(p_, d_, widest);
-    }
     Timer tall(stats != nullptr, stream_), tbr(stats != nullptr, stream_), tks(stats != nullptr, stream_);
     tall.mark();
     // inputs -> slots 0..n_inputs-1 of every expression

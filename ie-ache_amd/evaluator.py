@@ -141,6 +141,7 @@ def lib():
     L.ieache_mux.argtypes = [vp, C.c_size_t, i32p, i32p, i32p, i32p, sp]
     L.ieache_eval_batch.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, i32p, i32p, sp]
     L.ieache_eval_batch_device.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, vp, sp]
+    L.ieache_prepare_batch.argtypes = [vp, C.c_int, C.c_int, C.c_size_t]
     L.ieache_gates_device.argtypes = [vp, C.c_int, C.c_size_t, vp, vp, vp, sp]
     L.ieache_gates.argtypes = [vp, C.c_int, C.c_size_t, i32p, i32p, i32p, sp]
     L.ieache_debug_blind_rotate.argtypes = [vp, C.c_size_t, i32p, i32p, C.c_int32]
@@ -313,6 +314,11 @@ class Context:
         check(lib().ieache_eval_batch(self.h, kind, bits, batch, _i32(in_lwe), _i32(out),
                                       C.byref(stats) if stats is not None else None))
         return out
+
+    def prepare(self, kind, bits, batch):
+        """Allocates what eval_batch* of this circuit and batch needs (circuit tables, wire store, scratch), so that a timed
+        first evaluation measures the steady state."""
+        check(lib().ieache_prepare_batch(self.h, kind, bits, batch))
 
     def eval_batch_device(self, kind, bits, batch, d_in, d_out, stats=None):
         """Device pointers (ints); rows of lwe_stride int32."""

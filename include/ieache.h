@@ -216,6 +216,11 @@ int ieache_eval_batch(ieache_ctx* ctx, int kind, int bits, size_t batch, const i
 /* device buffers: rows of ieache_lwe_stride() int32 */
 int ieache_eval_batch_device(ieache_ctx* ctx, int kind, int bits, size_t batch, const int32_t* d_in, int32_t* d_out,
                              ieache_stats* stats);
+/* Builds (and caches) the circuit and allocates everything ieache_eval_batch*(ctx, kind, bits, batch, ...) needs on the
+ * device -- wire store, gate tables, scratch of the widest level -- so that the evaluation itself allocates nothing.
+ * Optional: the evaluation does the same on first use (the reference has no counterpart: ./cloud allocates per run,
+ * cloud.c:651-700). */
+int ieache_prepare_batch(ieache_ctx* ctx, int kind, int bits, size_t batch);
 /* `count` independent gates: out[i] = gate(a[i], b[i]); replaces bootsAND /
  * bootsXOR / bootsOR / bootsNAND (cloud.c:30-43,159).  Device rows. */
 int ieache_gates_device(ieache_ctx* ctx, int gate_type, size_t count, const int32_t* d_a, const int32_t* d_b,

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-3 measurement set on one MI355X (run through gpurun from the repo root; stages keep each call under gpurun's limit):
+# Round-4 measurement set on one MI355X (run through gpurun from the repo root; stages keep each call under gpurun's limit):
 #   driver: the driver's bench command (all legs) -> the JSON line
 #   stats:  the primary leg alone, then the whole default command, under rocprofv3 --kernel-trace --stats
-#   pmc:    PMC passes over the blind-rotation / key-switch microbenchmark
+#   pmc / pmc_x1: PMC passes over the blind-rotation / key-switch microbenchmark (one-limb default / exact_fft)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r3_meas
+OUT=gpurun_out/r4_meas
 mkdir -p $OUT
 for stage in "$@"; do
 case $stage in
@@ -22,5 +22,9 @@ pmc)
   rm -rf $OUT/pmc
   bash scripts/pmc_passes.sh $OUT/pmc python3 scripts/br_bench.py 8192 > $OUT/pmc.log 2>&1 || echo "pmc failed"
   tail -50 $OUT/pmc/summary.txt || true ;;
+pmc_x1)   # the same passes over the two-limb one-wave-per-gate kernel (exact_fft)
+  rm -rf $OUT/pmc_x1
+  EXACT_FFT=1 bash scripts/pmc_passes.sh $OUT/pmc_x1 python3 scripts/br_bench.py 8192 > $OUT/pmc_x1.log 2>&1 || echo "pmc_x1 failed"
+  tail -50 $OUT/pmc_x1/summary.txt || true ;;
 esac
 done

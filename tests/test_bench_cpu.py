@@ -81,6 +81,15 @@ def test_self_launch_builds_a_torchrun_command_and_relays(bench, monkeypatch, ca
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "3", "--steps", "2"]
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert capsys.readouterr().out == '{"n_gpus": 3}\n'
-    # more RCCL ranks than GPUs on the node: refused before anything is started (this container has no GPU at all)
+    # more RCCL ranks than GPUs on the node: refused before anything is started.  The launcher counts GPUs from the kernel
+    # driver's topology files, never through HIP / torch (it must not hold a GPU context while its ranks run) ...
     seen.clear()
+    monkeypatch.setattr(bench, "count_gpus_without_runtime", lambda: 2)
     assert bench.self_launch(types.SimpleNamespace(gpus=3, backend="nccl")) == 2 and not seen
+    # ... and where those files do not say (no KFD sysfs, as in this container) it starts the ranks and lets them report
+    monkeypatch.undo()
+    assert bench.count_gpus_without_runtime() in (None, 0) or bench.count_gpus_without_runtime() > 0
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3"])
+    monkeypatch.setattr(bench, "count_gpus_without_runtime", lambda: None)
+    assert bench.self_launch(types.SimpleNamespace(gpus=3, backend="nccl")) == 7 and seen["cmd"][1:3] == ["-m", "torch.distributed.run"]

@@ -837,6 +837,9 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     ctx.set_option("ks_mfma_min", 64)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("ks_gates", 12)
+    for bad in (3, 5, 48):                                 # K splits that do not divide the walk are refused when set, not mid-evaluation
+        with pytest.raises(ia.IeacheError):
+            ctx.set_option("ks_mfma_split", bad)
     ctx.force_generic(True)
     assert ctx.kernel_variant == "generic-radix2"
     assert np.array_equal(ctx.gates(ia.GATE_AND, a[:64], b[:64]), ref[:64])
@@ -1069,9 +1072,63 @@ def test_full_config_add16_batch4096_decrypts(ia, gpu_ctx):
     b = (inb[:, bits:2 * bits] * w).sum(1)
     got = (dec.astype(np.int64) * w).sum(1)
     assert np.array_equal(got, (a + b) & 0xFFFF)
-    e = 1234
-    s, _ = kb.ck.add(inp[e, :bits], inp[e, bits:2 * bits], inp[e, 2 * bits:2 * bits + 1], bits)  # 80 oracle bootstraps
-    assert np.array_equal(s, out[e])
+    # sixteen sampled expressions against the ORACLE bit for bit: the first and the last slot, the carry-through slot, the
+    # all-zero slot and twelve random ones -- cloud.c's add() (cloud.c:18-51) replayed level by level so that the sixteen
+    # expressions' gates of a level run as one batch on all host cores (1 280 oracle bootstraps)
+    sample = sorted({0, 1, B - 1, 1234} | set(int(v) for v in np.random.default_rng(16).choice(B, size=14, replace=False)))[:16]
+    ref = _oracle_add_batch(kb.ck, inp[sample, :bits], inp[sample, bits:2 * bits], inp[sample, 2 * bits], bits)
+    for q, e in enumerate(sample):
+        assert np.array_equal(ref[q], out[e]), e
+
+
+def _oracle_add_batch(ck, x, y, c, bits):
+    """cloud.c add() (cloud.c:18-51; oracle/cloud_oracle.c orc_add) on E independent expressions at once: the same five gates
+    per bit in the same dependency order, each level's gates of all expressions as one orc_gates_batch call.
+    x, y: [E][bits][n+1], c: [E][n+1] (the carry-in sample) -> sum [E][bits][n+1]"""
+    E = x.shape[0]
+    carry = np.ascontiguousarray(c)
+    out = np.zeros_like(x)
+    for i in range(bits):
+        both = ck.gates_batch("xor", np.concatenate([x[:, i], y[:, i]]), np.concatenate([carry, carry]), threads=0)  # :30, :32
+        axc, bxc = both[:E], both[E:]
+        out[:, i] = ck.gates_batch("xor", x[:, i], bxc, threads=0)        # :38
+        axc = ck.gates_batch("and", axc, bxc, threads=0)                  # :40
+        carry = ck.gates_batch("xor", carry, axc, threads=0)              # :43
+    return out
+
+
+def test_full_config_mul32_batch1024_slot0_matches_golden(ia, gpu_ctx):
+    """BASELINE.json configs[2] at full size -- the bench leg's geometry: 32-bit shift-add MUL x 1024 expressions, levels of
+    up to 1 056 x 1 024 gate instances cut into 65 536-gate launches (11.5 M bootstraps) -- with the golden vector's operand
+    pair in slot 0: that slot's 64 output samples must hash to tests/golden/mul32_n630.json (the oracle's bits, through the
+    chunked widest-launch path), and every one of the 1 024 products must decrypt to a * b."""
+    import hashlib
+    from ieache_amd.tools import bits_to_int, int_to_bits
+    g = json.load(open(os.path.join(G, "mul32_n630.json")))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(g["key_seed"]))
+    B = 1024
+    rng = np.random.default_rng(1024)
+    inb = rng.integers(0, 2, size=(B, 96), dtype=np.uint8)
+    inb[:, 64:] = 0                                         # the carry word encrypts 0 (alice.c:147-149)
+    inb[0, :32], inb[0, 32:64] = int_to_bits(g["a"], 32), int_to_bits(g["b"], 32)
+    inb[1, :64] = 1                                         # 0xFFFFFFFF x 0xFFFFFFFF
+    inp = kb.enc(inb, 2048)
+    gold_in = kb.enc(inb[0], g["encrypt_seed"])
+    assert hashlib.sha256(np.ascontiguousarray(gold_in).tobytes()).hexdigest() == g["input_sha256"]
+    inp[0] = gold_in
+    widest = ia.circuit_info(4, 32).max_width * B
+    assert widest > 65536 and ctx.kernel_for_launch(65536).startswith("k_blind_rotate_w1b")
+    st = ia.Stats()
+    out = ctx.eval_batch(4, 32, inp, st)
+    assert st.bootstraps == 11264 * B and st.chunks > st.levels == 255   # the wide levels were cut into several launches
+    assert hashlib.sha256(np.ascontiguousarray(out[0]).tobytes()).hexdigest() == g["output_sha256"]
+    w = 1 << np.arange(32, dtype=np.uint64)
+    a = (inb[:, :32].astype(np.uint64) * w).sum(1)
+    b = (inb[:, 32:64].astype(np.uint64) * w).sum(1)
+    dec = kb.dec(out)
+    for e in range(B):
+        assert bits_to_int(dec[e]) == int(a[e]) * int(b[e]), e
+    assert ctx.fft_guard()[0] < 1 / 32
 
 
 def test_old_libtfhe_parameter_set_on_fast_kernel(ia, gpu_ctx):
@@ -1090,7 +1147,7 @@ def test_old_libtfhe_parameter_set_on_fast_kernel(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), out)
     # this set's sums (4 x 1024 x 2^9 x 2^31 = 2^52) leave the one-limb transform too little FP64 headroom: the context
     # stays on the two-limb kernels and says so; forced, the one-limb kernels still agree (or trip the guard and repeat)
-    assert ctx.kernel_variant == "w2x64-radix8-registers" and ctx.fft_guard() == (0.0, 0)
+    assert ctx.kernel_variant == "x1x64-radix8-twolimb" and ctx.fft_guard() == (0.0, 0)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("exact_fft", 0)
     for variant in (31, 36):
@@ -1318,6 +1375,37 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     assert m["folded"]["executed_bootstraps_per_expr"] == 7568 and m["carry_save"]["levels"] == 37
     ma = out["muladd64"]
     assert ma["batch_per_gpu"] == 2 and ma["bootstraps_per_expr"] == 35936 and ma["roofline"]["frac"] > 0 and "mul128" not in out
+
+
+@pytest.mark.gpu
+def test_bench_default_command_shape_with_six_ranks_on_one_gpu(tmp_path):
+    """First-contact rehearsal of the multi-GPU job: the DEFAULT command shape -- every leg: add16 steps, the exact leg, mul32,
+    muladd64, mul128 -- with `--gpus 6`, started by bench.py itself, ranks wrapping onto this box's one GPU, CPU
+    collectives.  Six, not eight: this pool allows at most six processes on a card (the eight-rank plumbing runs on CPU in
+    tests/test_multirank_cpu.py).  One JSON line, every per-rank list six long, the key broadcast timed, inside the time box."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "6", "--backend", "gloo", "--batch", "64", "--legs",
+           "mul32,muladd64,mul128", "--mul32-batch", "8", "--muladd64-batch", "4", "--mul128-batch", "2", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp_path,
+                       env=dict(env, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 6 and out["scaling"] == "weak" and out["value"] > 0 and wall < 300, wall
+    cfg = out["config"]
+    assert cfg["key_broadcast_s"] > 0 and cfg["collective_backend"] == "gloo" and cfg["parallelism"] == "batch-sharded x6"
+    assert len(cfg["per_rank_gate_ops_per_s"]) == 6
+    for leg in ("mul32", "muladd64", "mul128", "exact"):
+        assert len(out[leg]["per_rank_gate_ops_per_s"]) == 6 and out[leg]["gate_ops_per_s"] > 0, leg
+    assert out["exact"]["bit_identical_to_primary_leg"] is True and out["exact"]["roofline"]["algorithmic_flops_per_gate"] == 630 * 328704
+    assert out["metric_leg"]["mul32_per_s"] == out["mul32_per_s"] > 0 and "skipped_legs" not in out
 
 
 @pytest.mark.gpu

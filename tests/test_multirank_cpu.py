@@ -1,5 +1,5 @@
-"""The N>1 path on CPU: two gloo ranks broadcast the cloud key, shard a batch of
-expressions with no data-path collective, and gather on the host.  (On the GPU
+"""The N>1 path on CPU: two -- and eight, the node size the job is written for -- gloo ranks broadcast the cloud key,
+shard a batch of expressions with no data-path collective, and gather on the host.  (On the GPU
 box the same functions run over RCCL; there is nothing else between ranks.)"""
 import os
 import socket
@@ -18,15 +18,15 @@ WORKER = textwrap.dedent("""
     import ieache_amd as ia
     from ieache_amd import parallel, tools
     rank, world, local_rank, dist = parallel.init_distributed("gloo")
-    assert world == 2 and dist is not None
+    assert world == int(os.environ["WORLD_SIZE"]) and dist is not None
     p = ia.default_params().copy(n=7, N=32)
     keys = tools.keygen_raw(p, (9, 9, 9)) if rank == 0 else None
     bk, ksk, lwe = parallel.broadcast_cloud_key(p, keys, torch.device("cpu"), dist)
     ref = tools.keygen_raw(p, (9, 9, 9))   # every rank can recompute what rank 0 sent
     assert np.array_equal(bk.numpy(), ref["bk"].ravel()) and np.array_equal(ksk.numpy(), ref["ksk"].ravel())
     assert np.array_equal(lwe.numpy(), ref["lwe_key"])
-    # shard 13 expressions of a 16-bit ADD; each rank evaluates only its own slice
-    total, bits = 13, 16
+    # shard 13 expressions (world 2) / 29 (world 8: ragged slices of 3 and 4) of a 16-bit ADD; each rank evaluates only its own slice
+    total, bits = (13 if world == 2 else 29), 16
     rng = np.random.default_rng(0)   # same operands on both ranks
     a = rng.integers(0, 1 << bits, size=total); b = rng.integers(0, 1 << bits, size=total)
     sl = parallel.shard_slice(total, rank, world)
@@ -58,15 +58,19 @@ def test_shard_slices_cover_batch_exactly():
     assert shard_slice(1024, 3, 8) == slice(384, 512)  # BASELINE config 4: 128 expressions per GPU
 
 
-def test_two_rank_gloo_broadcast_and_shard(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_ranks_broadcast_and_shard(tmp_path, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))

@@ -197,6 +197,23 @@ def test_key_reader_tolerates_other_layouts(ia, tmp_path):
         got = k2.reshape(-1, 4, S)
         assert np.array_equal(got[:, 1:], ksk4[:, 1:]) and not got[:, 0].any(), name
         assert want in L.ieache_last_key_layout(), (name, L.ieache_last_key_layout())
+    # a key whose d = 0 rows are NOT zero (a generator that encrypts h = 0 with noise like every other row): lweKeySwitch never
+    # reads those rows, so the key is as good as any and must load -- the all-zero property only breaks ties (below)
+    noisy = ksk4.copy()
+    noisy[:, 0] = np.random.default_rng(11).integers(-2 ** 31, 2 ** 31, size=noisy[:, 0].shape, dtype=np.int64).astype(np.int32)
+    assert ksk.tobytes() in body
+    f = tmp_path / "noisy_d0.key"
+    f.write_bytes(G + LW + TL + TG + body.replace(ksk.tobytes(), noisy.tobytes()))
+    q, b2, k2 = tools.read_cloud_key(f)
+    assert np.array_equal(b2, bk) and np.array_equal(k2.reshape(-1, 4, S)[:, 1:], ksk4[:, 1:]), L.ieache_last_key_layout()
+    # ... without tags or variances nothing is left to tell [KSK][BK] from [BK][KSK]: decoded right or refused, never shifted
+    f = tmp_path / "noisy_d0_bare.key"
+    f.write_bytes(G + LW + TL + TG + noisy.tobytes() + bk.tobytes())
+    try:
+        q, b2, k2 = tools.read_cloud_key(f)
+        assert np.array_equal(b2, bk) and np.array_equal(k2.reshape(-1, 4, S)[:, 1:], ksk4[:, 1:])
+    except ia.IeacheError as e:
+        assert "ambiguous key layout" in str(e)
     # layouts of EQUAL size that differ only in where a variance double stands (no tags to tell them apart): the first
     # eight bytes of a key-switch key that carries its d = 0 rows are zero and read as a perfectly plausible variance
     # 0.0, so [KSK][var][BK] also "fits" [var][KSK][BK] -- shifted by eight bytes.  The all-zero d = 0 rows decide.
