@@ -302,7 +302,8 @@ constexpr float kGuardLimit = 0.0625f;
 // Measured and dropped (profiles/r3_w1_ab.txt; source in git history, see attic/README.md): software-pipelined rows, both
 // forward transposes cross-lane, twiddles through the buffer path, an L2 prefetch of the next step's BK blocks.
 // dynamic LDS: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2          (78 848 B -> 2 per CU)
-template <int L, int BGBIT, int GUARD, bool DIAG = false>
+// FUSE: the register part of the twist folded into the first forward / last inverse radix-8 pass (fft512.h, round 4)
+template <int L, int BGBIT, int GUARD, bool DIAG = false, bool FUSE = false>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K, const double2* __restrict__ bkf1,
                                                                        const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                        int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -384,12 +385,12 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = (r == 0 || FUSE) ? make_double2((double)e0, (double)e1)
+                                        : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
             __builtin_amdgcn_sched_barrier(0);
             IEACHE_STAMP(1)
-            fft512_forward<true, 1>(x, sT, lane, R);
+            fft512_forward<true, 1, NoHook, false, false, FUSE>(x, sT, lane, R);
             IEACHE_STAMP(2)
             load_bk_block(bB, bk_rsrc, lane16, brow + kRowBytes / 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
         IEACHE_STAMP(0)
 #pragma unroll 1
         for (int row = L; row < 2 * L; row++) digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
-        fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
+        fft512_inverse_pair<true, FUSE>(s[0], s[1], sT, lane, R);
         IEACHE_STAMP(4)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -423,14 +424,15 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
             for (int r = 0; r < 8; r++) {
                 const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
                 double t0, t1;
-                if (r == 0) {
+                if (r == 0 || FUSE) {  // a real scale only: 1/512, and (FUSE) the cosines the last inverse pass left pending
+                    const double g = FUSE ? untwist_gain(r) : 1.0 / 512.0;
                     if (watched) {
-                        const double zx = s[c][0].x * (1.0 / 512.0), zy = s[c][0].y * (1.0 / 512.0);
+                        const double zx = s[c][r].x * g, zy = s[c][r].y * g;
                         t0 = zx + kMagic, t1 = zy + kMagic;
                         dev_max = fmax(dev_max, fabs(zx - (t0 - kMagic)));
                         dev_max = fmax(dev_max, fabs(zy - (t1 - kMagic)));
                     } else {
-                        t0 = fma(s[c][0].x, 1.0 / 512.0, kMagic), t1 = fma(s[c][0].y, 1.0 / 512.0, kMagic);
+                        t0 = fma(s[c][r].x, g, kMagic), t1 = fma(s[c][r].y, g, kMagic);
                     }
                 } else {
                     const double2 z = cmulx<true>(s[c][r], untwist_reg(r));
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
 // BK blocks are in flight at a time: block 0 of a row is requested inside its forward transform (once the second twiddle
 // set is consumed), block q + 2 when block q has been multiplied.  No guard: nothing here can round wrongly.
 // dynamic LDS as k_blind_rotate_w1b: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2   (78 848 B -> 2 per CU)
-template <int L, int BGBIT, bool BLOCKS = false>
+template <int L, int BGBIT, bool BLOCKS = false, bool FUSE = false>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K, const double2* __restrict__ bkf,
                                                                       const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                       int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -565,12 +567,12 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K,
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = (r == 0 || FUSE) ? make_double2((double)e0, (double)e1)
+                                        : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
             }
             __builtin_amdgcn_sched_barrier(0);
             auto req = [&]() { load_bk_block(bA, bk_rsrc, lane16, brow); };  // block 0: output 0, low limb
-            fft512_forward<true, 1, decltype(req), true, true>(x, sT, lane, R, req);
+            fft512_forward<true, 1, decltype(req), true, true, FUSE>(x, sT, lane, R, req);
             load_bk_block(bB, bk_rsrc, lane16, brow + kBlockBytes);          // block 1: output 0, high limb
             __builtin_amdgcn_sched_barrier(0);
             if (BLOCKS) {  // block granularity: block q + 2 requested when block q has been multiplied (A/B partner)
@@ -623,14 +625,15 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K,
         // back to coefficients: s[2 c] / s[2 c + 1] hold the low / high limb sums of output polynomial c
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            fft512_inverse_pair<true>(s[2 * c], s[2 * c + 1], sT, lane, R);
+            fft512_inverse_pair<true, FUSE>(s[2 * c], s[2 * c + 1], sT, lane, R);
             uint32_t* accc = reinterpret_cast<uint32_t*>(acc) + c * kN;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 double l0, l1, h0, h1;
-                if (r == 0) {
-                    l0 = fma(s[2 * c][0].x, 1.0 / 512.0, kMagic), l1 = fma(s[2 * c][0].y, 1.0 / 512.0, kMagic);
-                    h0 = fma(s[2 * c + 1][0].x, 1.0 / 512.0, kMagic), h1 = fma(s[2 * c + 1][0].y, 1.0 / 512.0, kMagic);
+                if (r == 0 || FUSE) {
+                    const double g = FUSE ? untwist_gain(r) : 1.0 / 512.0;
+                    l0 = fma(s[2 * c][r].x, g, kMagic), l1 = fma(s[2 * c][r].y, g, kMagic);
+                    h0 = fma(s[2 * c + 1][r].x, g, kMagic), h1 = fma(s[2 * c + 1][r].y, g, kMagic);
                 } else {
                     const double2 zl = cmulx<true>(s[2 * c][r], untwist_reg(r)), zh = cmulx<true>(s[2 * c + 1][r], untwist_reg(r));
                     l0 = zl.x + kMagic, l1 = zl.y + kMagic, h0 = zh.x + kMagic, h1 = zh.y + kMagic;
@@ -1402,9 +1405,9 @@ void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1
 
 bool variant_known(int32_t v) {
     switch (v) {
-        case 0: case kVariantTwoWavesLds: case kVariantWide: case kVariantWide + 1: case kVariantExactOneWave: case kVariantExactOneWave + 1:
+        case 0: case kVariantTwoWavesLds: case kVariantWide: case kVariantWide + 1: case kVariantExactOneWave: case kVariantExactOneWave + 1: case kVariantExactOneWave + 2:
         case kVariantWideOneLimb:
-        case kVariantOneLimbDefault: case kVariantOneLimbDefault + 1: case kVariantOneLimbDefault + 4: case kVariantOneLimbStamps:
+        case kVariantOneLimbDefault: case kVariantOneLimbDefault + 1: case kVariantOneLimbDefault + 2: case kVariantOneLimbDefault + 4: case kVariantOneLimbStamps:
         case kVariantOneLimbTwoWaves: case kVariantOneLimbTwoWaves + 1:
         case kVariantWideHandoverOneLimb: case kVariantWideHandoverOneLimb + 1:
         case kVariantOneLimbFourWaves: case kVariantOneLimbFourWaves + 1:
@@ -1497,6 +1500,10 @@ static void launch_slice(int variant, int64_t items, hipStream_t stream, const D
             IEACHE_ALLOW_LDS((k_blind_rotate_x1<L, BGBIT, true>), lds_w1)
             hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT, true>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf2, st_bara, nb, st_acc, items, i0, i1, e, gtw);
             break;
+        case kVariantExactOneWave + 2:  // ... twist folded into the radix-8 passes (round 4 A/B)
+            IEACHE_ALLOW_LDS((k_blind_rotate_x1<L, BGBIT, false, true>), lds_w1)
+            hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT, false, true>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf2, st_bara, nb, st_acc, items, i0, i1, e, gtw);
+            break;
         case kVariantWide:  // 2L waves per gate (latency)
             IEACHE_ALLOW_LDS((k_blind_rotate_wide<L, BGBIT, false, 2>), 160 * 1024)
             hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false, 2>), per_gate, dim3(128 * L), lds_wide, stream, K, bkf2, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw, (unsigned*)nullptr);
@@ -1521,6 +1528,10 @@ static void launch_slice(int variant, int64_t items, hipStream_t stream, const D
         case kVariantOneLimbDefault + 4:  // ... no guard arithmetic (measurement)
             IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 0>), lds_w1)
             hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, 0>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf1, st_bara, nb, st_acc, items, i0, i1, e, guard, gtw, nodiag);
+            break;
+        case kVariantOneLimbDefault + 2:  // ... twist folded into the radix-8 passes (round 4 A/B)
+            IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 2, false, true>), lds_w1)
+            hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, 2, false, true>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf1, st_bara, nb, st_acc, items, i0, i1, e, guard, gtw, nodiag);
             break;
         case kVariantOneLimbStamps:  // ... with phase stamps
             IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 2, true>), lds_w1)
