@@ -58,7 +58,6 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
     double dev_max = 0.0;
     constexpr int kRowBytes = 2 * kM * (int)sizeof(double2), kStepBytes = 2 * L * kRowBytes;
     const __amdgpu_buffer_rsrc_t bk_rsrc =
@@ -90,8 +89,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
             }
             if (EARLYB == 1) {
                 load_bk_block(bB, bk_rsrc, lane16, brow + kRowBytes / 2);
@@ -137,12 +135,11 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1(DevKeys K,
             uint32_t* accc = reinterpret_cast<uint32_t*>(acc) + c * kN;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const double2 z = r == 0 ? make_double2(s[c][0].x * (1.0 / 512.0), s[c][0].y * (1.0 / 512.0))
-                                         : cmulx<true>(s[c][r], untwist_reg(r));
-                const double t0 = z.x + kMagic, t1 = z.y + kMagic;
+                const double2 z = make_double2(s[c][r].x * untwist_gain(r), s[c][r].y * untwist_gain(r));
+                const double t0 = z.x + kMagic52, t1 = z.y + kMagic52;
                 if (GUARD) {
-                    dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
-                    dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
+                    dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic52)));
+                    dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic52)));
                 }
                 const int32_t j = 64 * r + lane;
                 // ds_add_u32 (no return): one LDS instruction instead of read, add, write
@@ -213,7 +210,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const do
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
     int32_t* accw = acc + wave * kN;  // the polynomial this wave decomposes and updates
     double dev_max = 0.0;
 
@@ -245,8 +241,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const do
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
             }
             __builtin_amdgcn_sched_barrier(0);
             auto req = [&]() {  // the partner row's block, requested once the transform's twiddle registers are free
@@ -279,11 +274,11 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2s(DevKeys K, const do
         uint32_t* accu = reinterpret_cast<uint32_t*>(accw);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
-            const double t0 = z.x + kMagic, t1 = z.y + kMagic;
+            const double2 z = make_double2(s[r].x * untwist_gain(r), s[r].y * untwist_gain(r));
+            const double t0 = z.x + kMagic52, t1 = z.y + kMagic52;
             if (GUARD) {
-                dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
-                dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
+                dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic52)));
+                dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic52)));
             }
             const int32_t j = 64 * r + lane;
             __hip_atomic_fetch_add(&accu[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -361,7 +356,6 @@ __global__ __launch_bounds__(128 * L, 3) void k_blind_rotate_wide4b(DevKeys K, c
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;
     const int pw = wave / L, qw = wave - pw * L;  // forward role: digit qw of polynomial pw = row `wave` of BK_i
     const int sh = 32 - (qw + 1) * BGBIT;
     const bool is_out = wave < 4;
@@ -402,8 +396,7 @@ __global__ __launch_bounds__(128 * L, 3) void k_blind_rotate_wide4b(DevKeys K, c
             // digit - halfBg = sign-extended field of (u ^ (halfBg << sh))
             const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)(u0 ^ (halfBg << sh)), sh, BGBIT);
             const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
-            x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                          : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
         }
         fft512_forward<true>(x, sT, lane, R);
 #pragma unroll
@@ -441,9 +434,9 @@ __global__ __launch_bounds__(128 * L, 3) void k_blind_rotate_wide4b(DevKeys K, c
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
-                const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
-                const double t0 = z.x + kMagic, t1 = z.y + kMagic;
-                if (watched) dev_max = fmax(dev_max, fmax(fabs(z.x - (t0 - kMagic)), fabs(z.y - (t1 - kMagic))));
+                const double2 z = make_double2(s[r].x * untwist_gain(r), s[r].y * untwist_gain(r));
+                const double t0 = z.x + kMagic52, t1 = z.y + kMagic52;
+                if (watched) dev_max = fmax(dev_max, fmax(fabs(z.x - (t0 - kMagic52)), fabs(z.y - (t1 - kMagic52))));
                 const int32_t j = 64 * r + lane;
                 atomicAdd(&acco[j], (uint32_t)__double2loint(t0));  // ds_add_u32; the other half of this output adds to the same word
                 atomicAdd(&acco[j + kM], (uint32_t)__double2loint(t1));
@@ -516,7 +509,6 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide1(DevKeys K, const
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;
     const int pw = wave / L, qw = wave - pw * L;  // digit qw of polynomial pw = row `wave` of BK_i
     const int sh = 32 - (qw + 1) * BGBIT;
     const int32_t* accp = acc + pw * kN;
@@ -558,8 +550,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide1(DevKeys K, const
             const uint32_t u1 = ((rv1[r] ^ n1) - n1) - pv1[r] + dec_offset;
             const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)(u0 ^ (halfBg << sh)), sh, BGBIT);
             const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
-            x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                          : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
         }
         __syncthreads();  // A: every wave has read the accumulator; from here on it may be added to
         fft512_forward<true, 1>(x, sT, lane, R);
@@ -572,12 +563,12 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide1(DevKeys K, const
         fft512_inverse_pair<true>(s0, s1, sT, lane, R);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const double2 z0 = r == 0 ? make_double2(s0[0].x * (1.0 / 512.0), s0[0].y * (1.0 / 512.0)) : cmulx<true>(s0[r], untwist_reg(r));
-            const double2 z1 = r == 0 ? make_double2(s1[0].x * (1.0 / 512.0), s1[0].y * (1.0 / 512.0)) : cmulx<true>(s1[r], untwist_reg(r));
-            const double t00 = z0.x + kMagic, t01 = z0.y + kMagic, t10 = z1.x + kMagic, t11 = z1.y + kMagic;
+            const double2 z0 = make_double2(s0[r].x * untwist_gain(r), s0[r].y * untwist_gain(r));
+            const double2 z1 = make_double2(s1[r].x * untwist_gain(r), s1[r].y * untwist_gain(r));
+            const double t00 = z0.x + kMagic52, t01 = z0.y + kMagic52, t10 = z1.x + kMagic52, t11 = z1.y + kMagic52;
             if (GUARD) {
-                dev_max = fmax(dev_max, fmax(fabs(z0.x - (t00 - kMagic)), fabs(z0.y - (t01 - kMagic))));
-                dev_max = fmax(dev_max, fmax(fabs(z1.x - (t10 - kMagic)), fabs(z1.y - (t11 - kMagic))));
+                dev_max = fmax(dev_max, fmax(fabs(z0.x - (t00 - kMagic52)), fabs(z0.y - (t01 - kMagic52))));
+                dev_max = fmax(dev_max, fmax(fabs(z1.x - (t10 - kMagic52)), fabs(z1.y - (t11 - kMagic52))));
             }
             const int32_t j = 64 * r + lane;
             atomicAdd(&accu[j], (uint32_t)__double2loint(t00));  // ds_add_u32: the 2L waves add their shares in any order

@@ -56,8 +56,7 @@ __global__ __launch_bounds__(64) void k_bk_to_spectrum_w64(const Torus32* bk_raw
             const int32_t lo0 = (int16_t)(v0 & 0xFFFF), lo1 = (int16_t)(v1 & 0xFFFF);
             const int32_t e0 = limb ? (int32_t)(((int64_t)v0 - lo0) >> 16) : lo0;
             const int32_t e1 = limb ? (int32_t)(((int64_t)v1 - lo1) >> 16) : lo1;
-            x[r] = r == 0 ? make_double2((double)e0, (double)e1)  // exp(0) = 1: nothing to multiply
-                            : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
         }
         fft512_forward<true>(x, sT, lane, R);
         double2* dst = bkf + ((irow * 4 + c * 2 + limb) * 8) * 64 + lane;
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(64) void k_bk_to_spectrum_w64_1(const Torus32* bk_r
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const double2 v = make_double2((double)src[64 * r + lane], (double)src[64 * r + lane + kM]);
-        x[r] = r == 0 ? v : cmulx<false>(v, twist_reg(r));
+        x[r] = v;
     }
     fft512_forward<true>(x, sT, lane, R);
     double2* dst = bkf1 + (poly * 8) * 64 + lane;
@@ -161,7 +160,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52: (x + magic) carries round(x) in its low mantissa bits
     int32_t* accw = acc + wave * kN;  // the polynomial this wave decomposes and updates
 
     // this slice's rotation amounts: one per lane, fetched once, then read with readlane
@@ -194,8 +192,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = r == 0 ? make_double2((double)e0, (double)e1)  // exp(0) = 1: nothing to multiply
-                            : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
             }
             // BK loads are issued well ahead of their use (each is an L2 round trip of ~700 cycles):
             //   bA = own row, limb 0      before the transform
@@ -250,10 +247,9 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2(DevKeys K, const dou
         fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const double2 zl = r == 0 ? make_double2(s[0][0].x * (1.0 / 512.0), s[0][0].y * (1.0 / 512.0)) : cmulx<true>(s[0][r], untwist_reg(r));
-            const double2 zh = r == 0 ? make_double2(s[1][0].x * (1.0 / 512.0), s[1][0].y * (1.0 / 512.0)) : cmulx<true>(s[1][r], untwist_reg(r));
-            const uint32_t l0 = (uint32_t)__double2loint(zl.x + kMagic), l1 = (uint32_t)__double2loint(zl.y + kMagic);
-            const uint32_t h0 = (uint32_t)__double2loint(zh.x + kMagic), h1 = (uint32_t)__double2loint(zh.y + kMagic);
+            double unused = 0.0;
+            const uint32_t l0 = round_coef(s[0][r].x, untwist_gain(r), false, unused), l1 = round_coef(s[0][r].y, untwist_gain(r), false, unused);
+            const uint32_t h0 = round_coef(s[1][r].x, untwist_gain(r), false, unused), h1 = round_coef(s[1][r].y, untwist_gain(r), false, unused);
             const int32_t j = 64 * r + lane;
             accw[j] = (int32_t)((uint32_t)accw[j] + l0 + (h0 << 16));
             accw[j + kM] = (int32_t)((uint32_t)accw[j + kM] + l1 + (h1 << 16));
@@ -302,8 +298,7 @@ constexpr float kGuardLimit = 0.0625f;
 // Measured and dropped (profiles/r3_w1_ab.txt; source in git history, see attic/README.md): software-pipelined rows, both
 // forward transposes cross-lane, twiddles through the buffer path, an L2 prefetch of the next step's BK blocks.
 // dynamic LDS: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2          (78 848 B -> 2 per CU)
-// FUSE: the register part of the twist folded into the first forward / last inverse radix-8 pass (fft512.h, round 4)
-template <int L, int BGBIT, int GUARD, bool DIAG = false, bool FUSE = false>
+template <int L, int BGBIT, int GUARD, bool DIAG = false>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K, const double2* __restrict__ bkf1,
                                                                        const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                        int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -336,7 +331,6 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
     double dev_max = 0.0;
     constexpr int kRowBytes = 2 * kM * (int)sizeof(double2), kStepBytes = 2 * L * kRowBytes;
     const __amdgpu_buffer_rsrc_t bk_rsrc =
@@ -385,12 +379,11 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = (r == 0 || FUSE) ? make_double2((double)e0, (double)e1)
-                                        : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
             }
             __builtin_amdgcn_sched_barrier(0);
             IEACHE_STAMP(1)
-            fft512_forward<true, 1, NoHook, false, false, FUSE>(x, sT, lane, R);
+            fft512_forward<true, 1>(x, sT, lane, R);
             IEACHE_STAMP(2)
             load_bk_block(bB, bk_rsrc, lane16, brow + kRowBytes / 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -415,7 +408,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
         IEACHE_STAMP(0)
 #pragma unroll 1
         for (int row = L; row < 2 * L; row++) digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
-        fft512_inverse_pair<true, FUSE>(s[0], s[1], sT, lane, R);
+        fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
         IEACHE_STAMP(4)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -423,28 +416,11 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
-                double t0, t1;
-                if (r == 0 || FUSE) {  // a real scale only: 1/512, and (FUSE) the cosines the last inverse pass left pending
-                    const double g = FUSE ? untwist_gain(r) : 1.0 / 512.0;
-                    if (watched) {
-                        const double zx = s[c][r].x * g, zy = s[c][r].y * g;
-                        t0 = zx + kMagic, t1 = zy + kMagic;
-                        dev_max = fmax(dev_max, fabs(zx - (t0 - kMagic)));
-                        dev_max = fmax(dev_max, fabs(zy - (t1 - kMagic)));
-                    } else {
-                        t0 = fma(s[c][r].x, g, kMagic), t1 = fma(s[c][r].y, g, kMagic);
-                    }
-                } else {
-                    const double2 z = cmulx<true>(s[c][r], untwist_reg(r));
-                    t0 = z.x + kMagic, t1 = z.y + kMagic;
-                    if (watched) {
-                        dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
-                        dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
-                    }
-                }
+                const uint32_t d0 = round_coef(s[c][r].x, untwist_gain(r), watched, dev_max), d1 = round_coef(s[c][r].y, untwist_gain(r), watched, dev_max);
                 const int32_t j = 64 * r + lane;
-                __hip_atomic_fetch_add(&accc[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&accc[j + kM], (uint32_t)__double2loint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                // ds_add_u32 (no return): one LDS instruction instead of read, add, write
+                __hip_atomic_fetch_add(&accc[j], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&accc[j + kM], d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
         wave_sync();
@@ -490,7 +466,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
 // BK blocks are in flight at a time: block 0 of a row is requested inside its forward transform (once the second twiddle
 // set is consumed), block q + 2 when block q has been multiplied.  No guard: nothing here can round wrongly.
 // dynamic LDS as k_blind_rotate_w1b: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2   (78 848 B -> 2 per CU)
-template <int L, int BGBIT, bool BLOCKS = false, bool FUSE = false>
+template <int L, int BGBIT, bool BLOCKS = false>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K, const double2* __restrict__ bkf,
                                                                       const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                       int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -522,7 +498,6 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K,
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
     constexpr int kBlockBytes = kM * (int)sizeof(double2), kRowBytes = 4 * kBlockBytes, kStepBytes = 2 * L * kRowBytes;
     const __amdgpu_buffer_rsrc_t bk_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(bkf), (short)0, K.n * kStepBytes, 0x00020000);
@@ -567,12 +542,11 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K,
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);  // v_bfe_i32
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = (r == 0 || FUSE) ? make_double2((double)e0, (double)e1)
-                                        : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
             }
             __builtin_amdgcn_sched_barrier(0);
             auto req = [&]() { load_bk_block(bA, bk_rsrc, lane16, brow); };  // block 0: output 0, low limb
-            fft512_forward<true, 1, decltype(req), true, true, FUSE>(x, sT, lane, R, req);
+            fft512_forward<true, 1, decltype(req), true, true>(x, sT, lane, R, req);
             load_bk_block(bB, bk_rsrc, lane16, brow + kBlockBytes);          // block 1: output 0, high limb
             __builtin_amdgcn_sched_barrier(0);
             if (BLOCKS) {  // block granularity: block q + 2 requested when block q has been multiplied (A/B partner)
@@ -625,22 +599,14 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K,
         // back to coefficients: s[2 c] / s[2 c + 1] hold the low / high limb sums of output polynomial c
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            fft512_inverse_pair<true, FUSE>(s[2 * c], s[2 * c + 1], sT, lane, R);
+            fft512_inverse_pair<true>(s[2 * c], s[2 * c + 1], sT, lane, R);
             uint32_t* accc = reinterpret_cast<uint32_t*>(acc) + c * kN;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                double l0, l1, h0, h1;
-                if (r == 0 || FUSE) {
-                    const double g = FUSE ? untwist_gain(r) : 1.0 / 512.0;
-                    l0 = fma(s[2 * c][r].x, g, kMagic), l1 = fma(s[2 * c][r].y, g, kMagic);
-                    h0 = fma(s[2 * c + 1][r].x, g, kMagic), h1 = fma(s[2 * c + 1][r].y, g, kMagic);
-                } else {
-                    const double2 zl = cmulx<true>(s[2 * c][r], untwist_reg(r)), zh = cmulx<true>(s[2 * c + 1][r], untwist_reg(r));
-                    l0 = zl.x + kMagic, l1 = zl.y + kMagic, h0 = zh.x + kMagic, h1 = zh.y + kMagic;
-                }
+                double unused = 0.0;  // nothing to watch: every rounded sum is below 2^35
+                const uint32_t d0 = round_coef(s[2 * c][r].x, untwist_gain(r), false, unused) + (round_coef(s[2 * c + 1][r].x, untwist_gain(r), false, unused) << 16);
+                const uint32_t d1 = round_coef(s[2 * c][r].y, untwist_gain(r), false, unused) + (round_coef(s[2 * c + 1][r].y, untwist_gain(r), false, unused) << 16);
                 const int32_t j = 64 * r + lane;
-                const uint32_t d0 = (uint32_t)__double2loint(l0) + ((uint32_t)__double2loint(h0) << 16);
-                const uint32_t d1 = (uint32_t)__double2loint(l1) + ((uint32_t)__double2loint(h1) << 16);
                 __hip_atomic_fetch_add(&accc[j], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_add(&accc[j + kM], d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
@@ -699,7 +665,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2r(DevKeys K, const do
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
     double dev_max = 0.0;
     constexpr int kRowBytes = 2 * kM * (int)sizeof(double2), kStepBytes = 2 * L * kRowBytes;
     const __amdgpu_buffer_rsrc_t bk_rsrc =
@@ -738,8 +703,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2r(DevKeys K, const do
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
             }
             __builtin_amdgcn_sched_barrier(0);
             fft512_forward<true, 1>(x, sT, lane, R);
@@ -778,27 +742,10 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_w2r(DevKeys K, const do
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
-            double t0, t1;
-            if (r == 0) {
-                if (watched) {
-                    const double zx = y[0].x * (1.0 / 512.0), zy = y[0].y * (1.0 / 512.0);
-                    t0 = zx + kMagic, t1 = zy + kMagic;
-                    dev_max = fmax(dev_max, fabs(zx - (t0 - kMagic)));
-                    dev_max = fmax(dev_max, fabs(zy - (t1 - kMagic)));
-                } else {
-                    t0 = fma(y[0].x, 1.0 / 512.0, kMagic), t1 = fma(y[0].y, 1.0 / 512.0, kMagic);
-                }
-            } else {
-                const double2 z = cmulx<true>(y[r], untwist_reg(r));
-                t0 = z.x + kMagic, t1 = z.y + kMagic;
-                if (watched) {
-                    dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
-                    dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
-                }
-            }
+            const uint32_t d0 = round_coef(y[r].x, untwist_gain(r), watched, dev_max), d1 = round_coef(y[r].y, untwist_gain(r), watched, dev_max);
             const int32_t j = 64 * r + lane;
-            __hip_atomic_fetch_add(&accu[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(&accu[j + kM], (uint32_t)__double2loint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&accu[j], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(&accu[j + kM], d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         wave_sync();  // wave w reads and updates only polynomial w: nothing crosses waves here
     }
@@ -871,7 +818,6 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate_w4r(DevKeys K, const do
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;  // 1.5 * 2^52
     double dev_max = 0.0;
     constexpr int kRowBytes = 2 * kM * (int)sizeof(double2), kStepBytes = 2 * L * kRowBytes;
     const __amdgpu_buffer_rsrc_t bk_rsrc =
@@ -919,8 +865,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate_w4r(DevKeys K, const do
             for (int r = 0; r < 8; r++) {
                 const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT);
                 const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                              : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+                x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
             }
             __builtin_amdgcn_sched_barrier(0);
             fft512_forward<true, 1>(x, sT, lane, R);
@@ -964,27 +909,10 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate_w4r(DevKeys K, const do
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
-                double t0, t1;
-                if (r == 0) {
-                    if (watched) {
-                        const double zx = y[0].x * (1.0 / 512.0), zy = y[0].y * (1.0 / 512.0);
-                        t0 = zx + kMagic, t1 = zy + kMagic;
-                        dev_max = fmax(dev_max, fabs(zx - (t0 - kMagic)));
-                        dev_max = fmax(dev_max, fabs(zy - (t1 - kMagic)));
-                    } else {
-                        t0 = fma(y[0].x, 1.0 / 512.0, kMagic), t1 = fma(y[0].y, 1.0 / 512.0, kMagic);
-                    }
-                } else {
-                    const double2 z = cmulx<true>(y[r], untwist_reg(r));
-                    t0 = z.x + kMagic, t1 = z.y + kMagic;
-                    if (watched) {
-                        dev_max = fmax(dev_max, fabs(z.x - (t0 - kMagic)));
-                        dev_max = fmax(dev_max, fabs(z.y - (t1 - kMagic)));
-                    }
-                }
+                const uint32_t d0 = round_coef(y[r].x, untwist_gain(r), watched, dev_max), d1 = round_coef(y[r].y, untwist_gain(r), watched, dev_max);
                 const int32_t j = 64 * r + lane;
-                __hip_atomic_fetch_add(&accu[j], (uint32_t)__double2loint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(&accu[j + kM], (uint32_t)__double2loint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&accu[j], d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(&accu[j + kM], d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
         __syncthreads();  // accumulator complete; every handed-over sum consumed; the tiles are scratch again
@@ -1058,7 +986,6 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;
     const int pw = wave / L, qw = wave - pw * L;  // forward role: digit qw of polynomial pw
     const int sh = 32 - (qw + 1) * BGBIT;
     const int32_t* accp = acc + pw * kN;
@@ -1119,8 +1046,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
             // digit - halfBg = sign-extended field of (u ^ (halfBg << sh))
             const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)(u0 ^ (halfBg << sh)), sh, BGBIT);
             const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
-            x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                          : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
         }
         IEACHE_STAMP(0)
         fft512_forward<true>(x, sT, lane, R);
@@ -1173,11 +1099,8 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
             fft512_inverse<true>(s, sT, lane, R);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
-                const double t0 = z.x + kMagic, t1 = z.y + kMagic;
-                if (LIMBS == 1) dev_max = fmax(dev_max, fmax(fabs(z.x - (t0 - kMagic)), fabs(z.y - (t1 - kMagic))));
-                const uint32_t c0 = (uint32_t)__double2loint(t0) << lsh;
-                const uint32_t c1 = (uint32_t)__double2loint(t1) << lsh;
+                const uint32_t c0 = round_coef(s[r].x, untwist_gain(r), LIMBS == 1, dev_max) << lsh;
+                const uint32_t c1 = round_coef(s[r].y, untwist_gain(r), LIMBS == 1, dev_max) << lsh;
                 const int32_t j = 64 * r + lane;
                 atomicAdd(&acco[j], c0);       // ds_add_u32; the partner limb adds its share to the same word
                 atomicAdd(&acco[j + kM], c1);
@@ -1257,7 +1180,6 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
     uint32_t dec_offset = 0;
 #pragma unroll
     for (int q = 1; q <= L; q++) dec_offset += halfBg << (32 - q * BGBIT);
-    constexpr double kMagic = 6755399441055744.0;
     const int pw = wave / L, qw = wave - pw * L;  // forward role: digit qw of polynomial pw = row `wave` of BK_i
     const int sh = 32 - (qw + 1) * BGBIT;
     const bool is_out = wave < 4;
@@ -1306,8 +1228,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
             // digit - halfBg = sign-extended field of (u ^ (halfBg << sh))
             const int32_t e0 = __builtin_amdgcn_sbfe((int32_t)(u0 ^ (halfBg << sh)), sh, BGBIT);
             const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
-            x[r] = r == 0 ? make_double2((double)e0, (double)e1)
-                          : cmulx<false>(make_double2((double)e0, (double)e1), twist_reg(r));
+            x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
         }
         fft512_forward<true>(x, sT, lane, R);
 #pragma unroll
@@ -1329,12 +1250,10 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const bool watched = GUARD == 1 || (GUARD == 2 && (r & 3) == 0);
-                const double2 z = r == 0 ? make_double2(s[0].x * (1.0 / 512.0), s[0].y * (1.0 / 512.0)) : cmulx<true>(s[r], untwist_reg(r));
-                const double t0 = z.x + kMagic, t1 = z.y + kMagic;
-                if (watched) dev_max = fmax(dev_max, fmax(fabs(z.x - (t0 - kMagic)), fabs(z.y - (t1 - kMagic))));
+                const uint32_t d0 = round_coef(s[r].x, untwist_gain(r), watched, dev_max), d1 = round_coef(s[r].y, untwist_gain(r), watched, dev_max);
                 const int32_t j = 64 * r + lane;
-                atomicAdd(&acco[j], (uint32_t)__double2loint(t0));  // ds_add_u32; the other half of this output adds to the same word
-                atomicAdd(&acco[j + kM], (uint32_t)__double2loint(t1));
+                atomicAdd(&acco[j], d0);  // ds_add_u32; the other half of this output adds to the same word
+                atomicAdd(&acco[j + kM], d1);
             }
         }
         __syncthreads();  // C: accumulator complete before the next decomposition; every published spectrum consumed
@@ -1405,9 +1324,9 @@ void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1
 
 bool variant_known(int32_t v) {
     switch (v) {
-        case 0: case kVariantTwoWavesLds: case kVariantWide: case kVariantWide + 1: case kVariantExactOneWave: case kVariantExactOneWave + 1: case kVariantExactOneWave + 2:
+        case 0: case kVariantTwoWavesLds: case kVariantWide: case kVariantWide + 1: case kVariantExactOneWave: case kVariantExactOneWave + 1:
         case kVariantWideOneLimb:
-        case kVariantOneLimbDefault: case kVariantOneLimbDefault + 1: case kVariantOneLimbDefault + 2: case kVariantOneLimbDefault + 4: case kVariantOneLimbStamps:
+        case kVariantOneLimbDefault: case kVariantOneLimbDefault + 1: case kVariantOneLimbDefault + 4: case kVariantOneLimbStamps:
         case kVariantOneLimbTwoWaves: case kVariantOneLimbTwoWaves + 1:
         case kVariantWideHandoverOneLimb: case kVariantWideHandoverOneLimb + 1:
         case kVariantOneLimbFourWaves: case kVariantOneLimbFourWaves + 1:
@@ -1500,10 +1419,6 @@ static void launch_slice(int variant, int64_t items, hipStream_t stream, const D
             IEACHE_ALLOW_LDS((k_blind_rotate_x1<L, BGBIT, true>), lds_w1)
             hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT, true>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf2, st_bara, nb, st_acc, items, i0, i1, e, gtw);
             break;
-        case kVariantExactOneWave + 2:  // ... twist folded into the radix-8 passes (round 4 A/B)
-            IEACHE_ALLOW_LDS((k_blind_rotate_x1<L, BGBIT, false, true>), lds_w1)
-            hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT, false, true>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf2, st_bara, nb, st_acc, items, i0, i1, e, gtw);
-            break;
         case kVariantWide:  // 2L waves per gate (latency)
             IEACHE_ALLOW_LDS((k_blind_rotate_wide<L, BGBIT, false, 2>), 160 * 1024)
             hipLaunchKernelGGL((k_blind_rotate_wide<L, BGBIT, false, 2>), per_gate, dim3(128 * L), lds_wide, stream, K, bkf2, st_bara, nb, st_acc, i0, i1, e, nodiag, gtw, (unsigned*)nullptr);
@@ -1528,10 +1443,6 @@ static void launch_slice(int variant, int64_t items, hipStream_t stream, const D
         case kVariantOneLimbDefault + 4:  // ... no guard arithmetic (measurement)
             IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 0>), lds_w1)
             hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, 0>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf1, st_bara, nb, st_acc, items, i0, i1, e, guard, gtw, nodiag);
-            break;
-        case kVariantOneLimbDefault + 2:  // ... twist folded into the radix-8 passes (round 4 A/B)
-            IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 2, false, true>), lds_w1)
-            hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, 2, false, true>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf1, st_bara, nb, st_acc, items, i0, i1, e, guard, gtw, nodiag);
             break;
         case kVariantOneLimbStamps:  // ... with phase stamps
             IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 2, true>), lds_w1)

@@ -304,7 +304,7 @@ __device__ __forceinline__ void xlane_hi(double2 (&x)[8]) {
 constexpr int kTile = 8 * 72;  // double2 elements per tile (9216 B)
 
 // Forward 512-point transform of the twisted polynomial.
-//   in : x[r] = y_{64r+lane} * exp(i*pi*r/16)  (the lane part tL of the twist is applied here)
+//   in : x[r] = y_{64r+lane}, untwisted (the first pass applies exp(i*pi*r/16), the first twiddle set the lane part tL)
 //   out: x[k2] = X[k0 + 8*k1 + 64*k2] with lane = 8*k0 + k1
 // XLANE = 1: the first (lane-high) transpose cross-lane (v_permlane*_swap / v_cndmask_b32_dpp) instead of through the tile.
 // MID: called once the first inter-pass twiddles are consumed (their 32 VGPRs are free from there on) or, MID_LATE, once
@@ -314,8 +314,7 @@ constexpr int kTile = 8 * 72;  // double2 elements per tile (9216 B)
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-// TWIST: x holds the UNtwisted coefficients; the first pass applies the register part of the twist itself (dft8_twist_fwd)
-template <bool WSYNC, int XLANE = 0, class MID = NoHook, bool MID_LATE = false, bool TBF = false, bool TWIST = false>
+template <bool WSYNC, int XLANE = 0, class MID = NoHook, bool MID_LATE = false, bool TBF = false>
 __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R, MID mid = MID()) {
     static_assert(XLANE == 0 || XLANE == 1, "lane-low transposes go through the tile");
     const int hi = lane >> 3, lo = lane & 7;
@@ -325,10 +324,7 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
     double2 tA[8], tB[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) tA[k] = R.a(k);
-    if (TWIST)
-        dft8_twist_fwd(x);                   // over r -> k0, e^{i pi r/16} included
-    else
-        dft8<false>(x);                      // over r -> k0
+    dft8_twist_fwd(x);                       // over r -> k0, the register part e^{i pi r/16} of the twist included
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = cmulx<false>(x[k], tA[k]);  // * tL * w512^(lane*k0)
     if (!std::is_same<MID, NoHook>::value && !MID_LATE) {
@@ -369,9 +365,9 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
 
 // Inverse of fft512_forward (unnormalised: 512 x), also removing the lane part of the twist:
 //   in : spectrum in the layout fft512_forward produces
-//   out: x[r] = y_{64r+lane} * exp(i*pi*r/16)   (caller multiplies by exp(-i*pi*r/16))
-// UNTWIST: the last pass removes the register part of the twist too, up to the real scales untwist_gain(r) (dft8_untwist_inv)
-template <bool WSYNC, bool UNTWIST = false>
+//   out: x[r] * untwist_gain(r) = y_{64r+lane}: untwisted and normalised up to one real factor per register, which the
+//        caller folds into the FMA that rounds (round_coef)
+template <bool WSYNC>
 __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R) {
     const int hi = lane >> 3, lo = lane & 7;
     const int own = hi * 9 + lo, blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
@@ -397,11 +393,8 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int
     for (int k0 = 0; k0 < 8; k0++) x[k0] = sT[own + 72 * k0];   // lane = (p1, p0)
     tile_sync<WSYNC>();
 #pragma unroll
-    for (int k = 0; k < 8; k++) x[k] = cmulx<true>(x[k], tA[k]);  // conj(tL * w1^k0); 1/512 is in untwist_reg()
-    if (UNTWIST)
-        dft8_untwist_inv(x);
-    else
-        dft8<true>(x);  // k0 -> r
+    for (int k = 0; k < 8; k++) x[k] = cmulx<true>(x[k], tA[k]);  // conj(tL * w1^k0)
+    dft8_untwist_inv(x);  // k0 -> r, e^{-i pi r/16} included up to untwist_gain(r)
 }
 
 // Two inverse transforms (the lo and hi limb sums of one output polynomial) interleaved in one
@@ -409,7 +402,7 @@ __device__ __forceinline__ void fft512_inverse(double2 (&x)[8], double2* sT, int
 // long as each [write, read] pair of one transform is issued whole, the other transform's
 // butterflies run while that round trip is in flight.  (Alone, a wave spends ~2/3 of a
 // transform waiting on its four LDS round trips.)
-template <bool WSYNC, bool UNTWIST = false>
+template <bool WSYNC>
 __device__ __forceinline__ void fft512_inverse_pair(double2 (&x)[8], double2 (&y)[8], double2* sT, int lane,
                                                     const LaneRoots& R) {
     const int hi = lane >> 3, lo = lane & 7;
@@ -452,38 +445,29 @@ __device__ __forceinline__ void fft512_inverse_pair(double2 (&x)[8], double2 (&y
     for (int k0 = 0; k0 < 8; k0++) y[k0] = sT[own + 72 * k0];    // y round trip 2 ...
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = cmulx<true>(x[k], tA[k]);
-    if (UNTWIST)
-        dft8_untwist_inv(x);
-    else
-        dft8<true>(x);                                            // ... under x's last pass
+    dft8_untwist_inv(x);                                          // ... under x's last pass
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 8; k++) y[k] = cmulx<true>(y[k], tA[k]);
-    if (UNTWIST)
-        dft8_untwist_inv(y);
-    else
-        dft8<true>(y);
+    dft8_untwist_inv(y);
     tile_sync<WSYNC>();  // the tile may be reused by the caller
 }
 
-// exp(i*pi*r/16), r = 0..7: the register part of the twist
-__device__ __forceinline__ double2 twist_reg(int r) {
-    constexpr double C[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
-                             0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
-                             0.19509032201612826785};
-    constexpr double S[8] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
-                             0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613,
-                             0.98078528040323044913};
-    return make_double2(C[r], S[r]);
+// Rounds one inverse-transformed coefficient: x * gain + 1.5 * 2^52 carries round(x * gain) in its low mantissa bits.  watch:
+// the product and the sum are separate operations and the distance to the nearest integer is folded into dev_max (the
+// one-limb kernels' rounding guard); otherwise one FMA.
+constexpr double kMagic52 = 6755399441055744.0;  // 1.5 * 2^52
+__device__ __forceinline__ uint32_t round_coef(double v, double gain, bool watch, double& dev_max) {
+    double t;
+    if (watch) {  // a compile-time constant at every call site once the register loop is unrolled
+        const double z = v * gain;
+        t = z + kMagic52;
+        dev_max = fmax(dev_max, fabs(z - (t - kMagic52)));
+    } else {
+        t = fma(v, gain, kMagic52);
+    }
+    return (uint32_t)__double2loint(t);
 }
-
-// exp(i*pi*r/16) / 512: multiplying by its conjugate removes the register part of the
-// twist and normalises the inverse transform (exact: a power-of-two scale)
-__device__ __forceinline__ double2 untwist_reg(int r) {
-    const double2 t = twist_reg(r);
-    return make_double2(t.x * (1.0 / 512.0), t.y * (1.0 / 512.0));
-}
-
 
 // One 8-register block [8][64] double2 of the BK spectrum through the buffer path: resource and byte offset in SGPRs,
 // the lane's 16 bytes as the only vector operand, the register index as the instruction's immediate (0-3 KiB) -- no
