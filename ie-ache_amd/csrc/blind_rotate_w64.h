@@ -41,7 +41,7 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 // (evaluator.hip: <= one gate per CU -> 38, <= 2 per CU -> 43, <= 5 per CU -> 36, above -> 31; "exact_fft": 7 / 0 / 9);
 // passed to launch() itself, 0 is the two-limb two-wave kernel.
 //   two limbs (exact by construction):
-//     9  k_blind_rotate_x1: one wave per gate (round 4; wide launches)      10  its BK blocks re-requested per block, not per register
+//     9  k_blind_rotate_x1: one wave per gate (round 4; wide launches)
 //     0  k_blind_rotate_w2: two waves per gate, split by output polynomial  12  every transpose through LDS (round 1)
 //     7  k_blind_rotate_wide: 2L waves per gate (latency; any slice length up to n)   8  with s_memtime phase stamps on stderr
 //   one limb with the rounding guard (on one rounded coefficient in four unless noted):

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
 // BK blocks are in flight at a time: block 0 of a row is requested inside its forward transform (once the second twiddle
 // set is consumed), block q + 2 when block q has been multiplied.  No guard: nothing here can round wrongly.
 // dynamic LDS as k_blind_rotate_w1b: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2   (78 848 B -> 2 per CU)
-template <int L, int BGBIT, bool BLOCKS = false>
+template <int L, int BGBIT>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K, const double2* __restrict__ bkf,
                                                                       const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                       int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -549,41 +549,18 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K,
             fft512_forward<true, 1, decltype(req), true, true>(x, sT, lane, R, req);
             load_bk_block(bB, bk_rsrc, lane16, brow + kBlockBytes);          // block 1: output 0, high limb
             __builtin_amdgcn_sched_barrier(0);
-            if (BLOCKS) {  // block granularity: block q + 2 requested when block q has been multiplied (A/B partner)
-                mac(s[0], x, bA, first);
-                __builtin_amdgcn_sched_barrier(0);
-                load_bk_block(bA, bk_rsrc, lane16, brow + 2 * kBlockBytes);
-                __builtin_amdgcn_sched_barrier(0);
-                mac(s[1], x, bB, first);
-                __builtin_amdgcn_sched_barrier(0);
-                load_bk_block(bB, bk_rsrc, lane16, brow + 3 * kBlockBytes);
-                __builtin_amdgcn_sched_barrier(0);
-                mac(s[2], x, bA, first);
-                mac(s[3], x, bB, first);
-            } else {
-                // register granularity: each 16-byte register of block q is re-requested for block q + 2 right behind the
-                // products that consumed it, so a request always has two blocks' worth of products (64 FMAs) to arrive under
-                constexpr bool FIRST = decltype(first)::value;
-#define IEACHE_X1_MAC2(S, B, NEXT, NEXT_OFF)                                                                              \
-    _Pragma("unroll") for (int k = 0; k < 8; k += 2) {                                                                  \
-        _Pragma("unroll") for (int kk = k; kk < k + 2; kk++)                                                            \
-            S[kk] = FIRST ? cmulx<false>(x[kk], B[kk])                                                                  \
-                          : make_double2(fma(x[kk].x, B[kk].x, fma(-x[kk].y, B[kk].y, S[kk].x)),                        \
-                                         fma(x[kk].x, B[kk].y, fma(x[kk].y, B[kk].x, S[kk].y)));                        \
-        if (NEXT) {                                                                                                     \
-            _Pragma("unroll") for (int kk = k; kk < k + 2; kk++) {                                                      \
-                const v4i_t d = __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane16 + (kk & 3) * 1024, (NEXT_OFF) + (kk >> 2) * 4096, 0); \
-                B[kk] = make_double2(__hiloint2double(d.y, d.x), __hiloint2double(d.w, d.z));                           \
-            }                                                                                                           \
-        }                                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                              \
-    }
-                IEACHE_X1_MAC2(s[0], bA, true, brow + 2 * kBlockBytes)
-                IEACHE_X1_MAC2(s[1], bB, true, brow + 3 * kBlockBytes)
-                IEACHE_X1_MAC2(s[2], bA, false, 0)
-                IEACHE_X1_MAC2(s[3], bB, false, 0)
-#undef IEACHE_X1_MAC2
-            }
+            // block q + 2 is requested when block q has been multiplied (re-requesting register by register, right behind the
+            // products that consumed each one, measured the same: profiles/r4_x1_ab.txt)
+            mac(s[0], x, bA, first);
+            __builtin_amdgcn_sched_barrier(0);
+            load_bk_block(bA, bk_rsrc, lane16, brow + 2 * kBlockBytes);            // block 2: output 1, low limb
+            __builtin_amdgcn_sched_barrier(0);
+            mac(s[1], x, bB, first);
+            __builtin_amdgcn_sched_barrier(0);
+            load_bk_block(bB, bk_rsrc, lane16, brow + 3 * kBlockBytes);            // block 3: output 1, high limb
+            __builtin_amdgcn_sched_barrier(0);
+            mac(s[2], x, bA, first);
+            mac(s[3], x, bB, first);
         };
         decompose(pb0, jb4);
         digit_row(32 - BGBIT, bki, std::true_type{});
@@ -1324,7 +1301,7 @@ void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1
 
 bool variant_known(int32_t v) {
     switch (v) {
-        case 0: case kVariantTwoWavesLds: case kVariantWide: case kVariantWide + 1: case kVariantExactOneWave: case kVariantExactOneWave + 1:
+        case 0: case kVariantTwoWavesLds: case kVariantWide: case kVariantWide + 1: case kVariantExactOneWave:
         case kVariantWideOneLimb:
         case kVariantOneLimbDefault: case kVariantOneLimbDefault + 1: case kVariantOneLimbDefault + 4: case kVariantOneLimbStamps:
         case kVariantOneLimbTwoWaves: case kVariantOneLimbTwoWaves + 1:
@@ -1412,12 +1389,8 @@ static void launch_slice(int variant, int64_t items, hipStream_t stream, const D
             hipLaunchKernelGGL((k_blind_rotate_w2<L, BGBIT, 0>), per_gate, dim3(128), lds_w2, stream, K, bkf2, st_bara, nb, st_acc, i0, i1, e, gtw);
             break;
         case kVariantExactOneWave:  // one wave per gate (round 4)
-            IEACHE_ALLOW_LDS((k_blind_rotate_x1<L, BGBIT, false>), lds_w1)
-            hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT, false>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf2, st_bara, nb, st_acc, items, i0, i1, e, gtw);
-            break;
-        case kVariantExactOneWave + 1:  // ... BK blocks re-requested at block granularity (A/B partner)
-            IEACHE_ALLOW_LDS((k_blind_rotate_x1<L, BGBIT, true>), lds_w1)
-            hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT, true>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf2, st_bara, nb, st_acc, items, i0, i1, e, gtw);
+            IEACHE_ALLOW_LDS((k_blind_rotate_x1<L, BGBIT>), lds_w1)
+            hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf2, st_bara, nb, st_acc, items, i0, i1, e, gtw);
             break;
         case kVariantWide:  // 2L waves per gate (latency)
             IEACHE_ALLOW_LDS((k_blind_rotate_wide<L, BGBIT, false, 2>), 160 * 1024)

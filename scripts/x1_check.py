@@ -21,10 +21,10 @@ assert np.array_equal(tools.decrypt_bits(p, k["lwe_key"], ref), bits[0] ^ bits[1
 reps = int(os.environ.get("REPS", "3"))
 for c in counts:
     for name, opts in (("w2", {"br_variant": 0, "exact_one_wave_min": 1 << 40, "br_slice": 0}),
-                       ("x1 queue (9)", {"br_variant": 9, "br_slice": 16}),
-                       ("x1 static (10)", {"br_variant": 10, "br_slice": 16}),
-                       ("x1 q blocks (11)", {"br_variant": 11, "br_slice": 16}),
-                       ("x1 (9) slice 32", {"br_variant": 9, "br_slice": 32})):
+                       ("x1 (9)", {"br_variant": 9, "br_slice": 16}),
+                       ("x1 blocks (10)", {"br_variant": 10, "br_slice": 16}),
+                       ("x1 xmix (11)", {"br_variant": 11, "br_slice": 16}),
+                       ("x1 (9) again", {"br_variant": 9, "br_slice": 16})):
         for o, v in opts.items():
             ctx.set_option(o, v)
         best = None

@@ -733,7 +733,7 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         ctx.set_option("br_slice", sl)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref), sl
     ctx.set_option("br_slice", 0)
-    for variant in (9, 10, 12):                            # two limbs: one wave per gate (BK re-requested per register / per block);
+    for variant in (9, 12):                                # two limbs: one wave per gate (round 4);
         ctx.set_option("br_variant", variant)              # two waves per gate with every transpose through LDS
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), variant   # ragged last workgroup of 4 gates
     ctx.set_option("br_variant", 9)
