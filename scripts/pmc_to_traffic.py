@@ -8,7 +8,7 @@ HBM bytes as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH
   python scripts/pmc_to_traffic.py profiles/r2_f_pmc_summary.txt [gates_per_launch=8192] [cmux_steps_per_launch=16] [kernel key]
 
 The kernel key is what ieache_ctx_kernel_variant() reports ("w1x64-radix8-onelimb", the default, or
-"w2x64-radix8-registers" with exact_fft); the other kernel's entry in traffic.json is kept.
+"x1x64-radix8-twolimb" with exact_fft); the other kernel's entry in traffic.json is kept.
 """
 import json
 import os
@@ -21,7 +21,8 @@ gates = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 key = sys.argv[4] if len(sys.argv) > 4 else "w1x64-radix8-onelimb"
 # FP64 instructions per gate and CMux step, counted in the kernels' ISA (scripts/isa_count.py)
-KERNELS = {"w1x64-radix8-onelimb": ("k_blind_rotate_w1b<3,7,guard on 1 coefficient in 4>", 2493), "w2x64-radix8-registers": ("k_blind_rotate_w2<3,7>", 3368)}
+# (round 4, twist folded into the radix-8 passes: profiles/r4_isa_mix.txt)
+KERNELS = {"w1x64-radix8-onelimb": ("k_blind_rotate_w1b<3,7,guard on 1 coefficient in 4>", 2425), "x1x64-radix8-twolimb": ("k_blind_rotate_x1<3,7>", 3280)}
 vals = {}
 for line in open(summary):
     m = re.match(r"(BR|KS) (\S+)\s+n=(\d+) avg=([0-9.e+-]+)", line)
@@ -63,7 +64,7 @@ out.update({
 # instructions takes per wave-instruction and SIMD with two waves per SIMD (scripts/ubench/valu_rates.hip,
 # profiles/r3_issue_costs.txt: FP64 arithmetic / conversions ~5.3 'cycles at 2.4 GHz' = 2.21 ns, the other vector
 # instructions ~4.5 = 1.875 ns; already at the clock the chip holds under FP64 load)
-if key == "w1x64-radix8-onelimb":
+if key in KERNELS:
     e = out[key]
     fp64, other = e["fp64_insts_per_gate_step"], e["valu_insts_per_gate_step"] - e["fp64_insts_per_gate_step"]
     t = fp64 * 2.21e-9 + other * 1.875e-9
@@ -75,10 +76,10 @@ for a in sys.argv[5:]:
         import csv
         f = a[6:]
         for row in csv.DictReader(open(f)):
-            if "k_blind_rotate_w1" in row["Name"] and "prologue" not in row["Name"]:
+            if KERNELS[key][0].split("<")[0] in row["Name"] and "prologue" not in row["Name"]:
                 out[key]["rocprof_avg_launch_ms"] = float(row["AverageNs"]) * 1e-6
                 out[key]["rocprof_calls"] = int(row["Calls"])
-                out[key]["rocprof_stats"] = os.path.relpath(os.path.abspath(f), ROOT) + " (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs none)"
+                out[key]["rocprof_stats"] = os.path.relpath(os.path.abspath(f), ROOT) + " (rocprofv3 --kernel-trace --stats -- python3 bench.py %s)" % ("--steps 3 --warmup 1 --no-cpu-baseline --legs none --exact-leg off" if key.startswith("w1") else "--steps 1 --warmup 1 --no-cpu-baseline --legs none: the primary leg, then the exact leg's two passes")
                 break
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out[key], indent=1))

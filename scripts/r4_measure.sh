@@ -14,8 +14,11 @@ driver)
   echo "driver command done"; tail -c 300 $OUT/bench_driver_cmd.json; echo ;;
 stats)
   rm -rf $OUT/stats_add16 $OUT/stats_all
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_add16 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs none > $OUT/add16_rocprof.json 2> $OUT/add16_rocprof.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_add16 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --legs none --exact-leg off > $OUT/add16_rocprof.json 2> $OUT/add16_rocprof.err
   find $OUT/stats_add16 -name "*kernel_stats.csv" | head -3
+  rm -rf $OUT/stats_exact   # the exact leg (two-limb kernels) beside it: primary leg + exact leg
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_exact -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --legs none > $OUT/exact_rocprof.json 2> $OUT/exact_rocprof.err
+  find $OUT/stats_exact -name "*kernel_stats.csv" | head -3
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_all -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/all_rocprof.json 2> $OUT/all_rocprof.err
   find $OUT/stats_all -name "*kernel_stats.csv" | head -3 ;;
 pmc)
