@@ -1378,17 +1378,17 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_default_command_shape_with_four_ranks_on_one_gpu(tmp_path):
+def test_bench_default_command_shape_with_three_ranks_on_one_gpu(tmp_path):
     """First-contact rehearsal of the multi-GPU job: the DEFAULT command shape -- every leg: add16 steps, the exact leg, mul32,
-    muladd64, mul128 -- with `--gpus 4`, started by bench.py itself, ranks wrapping onto this box's one GPU, CPU
-    collectives.  Four, not eight: this pool allows at most six processes on a card, and this test process and the launcher's
-    agent count (a six-rank attempt was killed by the box's process guard); the eight-rank plumbing runs on CPU in
-    tests/test_multirank_cpu.py.  One JSON line, every per-rank list four long, the key broadcast timed, inside the time box."""
+    muladd64, mul128 -- with `--gpus 3`, started by bench.py itself, ranks wrapping onto this box's one GPU, CPU
+    collectives.  Three, not eight: this pool allows at most six processes on a card, and this test process and the launcher's
+    agent count too (a six-rank attempt was killed by the box's process guard; four ran, at the limit); the eight-rank plumbing runs on CPU in
+    tests/test_multirank_cpu.py.  One JSON line, every per-rank list three long, the key broadcast timed, inside the time box."""
     import subprocess
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo", "--batch", "64", "--legs",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--backend", "gloo", "--batch", "64", "--legs",
            "mul32,muladd64,mul128", "--mul32-batch", "8", "--muladd64-batch", "4", "--mul128-batch", "2", "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     t0 = time.perf_counter()
@@ -1399,12 +1399,12 @@ def test_bench_default_command_shape_with_four_ranks_on_one_gpu(tmp_path):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 4 and out["scaling"] == "weak" and out["value"] > 0 and wall < 300, wall
+    assert out["n_gpus"] == 3 and out["scaling"] == "weak" and out["value"] > 0 and wall < 300, wall
     cfg = out["config"]
-    assert cfg["key_broadcast_s"] > 0 and cfg["collective_backend"] == "gloo" and cfg["parallelism"] == "batch-sharded x4"
-    assert len(cfg["per_rank_gate_ops_per_s"]) == 4
+    assert cfg["key_broadcast_s"] > 0 and cfg["collective_backend"] == "gloo" and cfg["parallelism"] == "batch-sharded x3"
+    assert len(cfg["per_rank_gate_ops_per_s"]) == 3
     for leg in ("mul32", "muladd64", "mul128", "exact"):
-        assert len(out[leg]["per_rank_gate_ops_per_s"]) == 4 and out[leg]["gate_ops_per_s"] > 0, leg
+        assert len(out[leg]["per_rank_gate_ops_per_s"]) == 3 and out[leg]["gate_ops_per_s"] > 0, leg
     assert out["exact"]["bit_identical_to_primary_leg"] is True and out["exact"]["roofline"]["algorithmic_flops_per_gate"] == 630 * 328704
     assert out["metric_leg"]["mul32_per_s"] == out["mul32_per_s"] > 0 and "skipped_legs" not in out
 
