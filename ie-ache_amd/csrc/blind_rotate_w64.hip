@@ -11,14 +11,19 @@
 //     so all resident workgroups read the same BK blocks while they are hot in the XCD's L2;
 //   * the accumulator (2 x 1024 int32) lives in LDS only because the X^a rotation needs arbitrary shifts; twiddles come from a
 //     9 KiB LDS table.
+//   * the 512-point complex transform is 8 x 8 x 8 (fft512.h) with the register part of the negacyclic twist folded into its
+//     first / last radix-8 pass.
 // One kernel per launch-size regime (variant table in blind_rotate_w64.h):
 //   k_blind_rotate_w1b    one wave per gate            launches of more than 5 gates per CU (the throughput kernel)
 //   k_blind_rotate_w2r    two waves per gate           2 .. 5 gates per CU
 //   k_blind_rotate_w4r    four waves per gate          1 .. 2 gates per CU
 //   k_blind_rotate_wide4  2L = 6 waves per gate        at most one gate per CU (single expressions: the reference's own mode)
 // all on the ONE-limb spectrum (libtfhe's own product, rounded to the exact integer under a rounding guard and a sampled
-// audit), and k_blind_rotate_w2 / k_blind_rotate_wide<..., 2> on the TWO-limb spectrum (exact by construction: "exact_fft",
-// repeats, audits).  Earlier kernels and measured dead ends stay selectable as A/B partners.
+// audit), and on the TWO-limb spectrum (exact by construction: "exact_fft", repeats, audits)
+//   k_blind_rotate_x1     one wave per gate            more than 4 gates per CU (round 4)
+//   k_blind_rotate_w2     two waves per gate           1 .. 4 gates per CU
+//   k_blind_rotate_wide   2L waves per gate            at most one gate per CU
+// Kernels and template flags that lost their A/B: attic/ (not built by default).
 #include "blind_rotate_w64.h"
 
 #include <cstdio>

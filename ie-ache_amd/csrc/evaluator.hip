@@ -605,7 +605,7 @@ void Evaluator::init() {
         d_->cus = cus;
         d_->br_wide_max = cus;  // one workgroup of the wide kernel fills a CU
         // k_blind_rotate_w1: one wave per gate, 256 VGPRs -> 2 per SIMD = 8 gates per CU
-        // (k_blind_rotate_w2, "exact_fft": 2 waves per gate, 35.8 KB of LDS -> 4 per CU)
+        // ("exact_fft": k_blind_rotate_x1 holds 8 gates per CU too; k_blind_rotate_w2, 2 waves per gate and 35.8 KB of LDS, 4 per CU)
         resident_gates_ = 8 * cus;
         d_->one_limb_min = cus + 1;  // everything the latency kernel does not take
         d_->four_wave_max = 2 * cus;
