@@ -303,8 +303,7 @@ constexpr float kGuardLimit = 0.0625f;
 // Measured and dropped (profiles/r3_w1_ab.txt; source in git history, see attic/README.md): software-pipelined rows, both
 // forward transposes cross-lane, twiddles through the buffer path, an L2 prefetch of the next step's BK blocks.
 // dynamic LDS: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2          (78 848 B -> 2 per CU)
-// PAIR (A/B, round 4): rows (0,1) and (L,L+1) transformed as interleaved pairs (fft512_forward_pair)
-template <int L, int BGBIT, int GUARD, bool DIAG = false, bool PAIR = false>
+template <int L, int BGBIT, int GUARD, bool DIAG = false>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K, const double2* __restrict__ bkf1,
                                                                        const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                        int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
@@ -405,58 +404,8 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
                                                fma(x[k].x, bB[k].y, fma(x[k].y, bB[k].x, s[1][k].y)));
             IEACHE_STAMP(3)
         };
-        auto digit_row_pair = [&](const int sh, const int brow, auto first) {  // rows brow and brow + kRowBytes: digits at sh and sh - BGBIT
-            constexpr bool FIRST = decltype(first)::value;
-            double2 xa[8], xb[8], bA[8], bB[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                // (the builtin returns unsigned: the digit is its bits read as int32)
-                const int32_t a0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh, BGBIT), a1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh, BGBIT);
-                const int32_t b0 = __builtin_amdgcn_sbfe((int32_t)v0[r], sh - BGBIT, BGBIT), b1 = __builtin_amdgcn_sbfe((int32_t)v1[r], sh - BGBIT, BGBIT);
-                xa[r] = make_double2((double)a0, (double)a1);
-                xb[r] = make_double2((double)b0, (double)b1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            auto req = [&]() { load_bk_block(bA, bk_rsrc, lane16, brow); };
-            fft512_forward_pair<true, decltype(req)>(xa, xb, sT, lane, R, req);
-            load_bk_block(bB, bk_rsrc, lane16, brow + kRowBytes / 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                s[0][k] = FIRST ? cmulx<false>(xa[k], bA[k])
-                                : make_double2(fma(xa[k].x, bA[k].x, fma(-xa[k].y, bA[k].y, s[0][k].x)),
-                                               fma(xa[k].x, bA[k].y, fma(xa[k].y, bA[k].x, s[0][k].y)));
-            __builtin_amdgcn_sched_barrier(0);
-            load_bk_block(bA, bk_rsrc, lane16, brow + kRowBytes);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                s[1][k] = FIRST ? cmulx<false>(xa[k], bB[k])
-                                : make_double2(fma(xa[k].x, bB[k].x, fma(-xa[k].y, bB[k].y, s[1][k].x)),
-                                               fma(xa[k].x, bB[k].y, fma(xa[k].y, bB[k].x, s[1][k].y)));
-            __builtin_amdgcn_sched_barrier(0);
-            load_bk_block(bB, bk_rsrc, lane16, brow + kRowBytes + kRowBytes / 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                s[0][k] = make_double2(fma(xb[k].x, bA[k].x, fma(-xb[k].y, bA[k].y, s[0][k].x)),
-                                       fma(xb[k].x, bA[k].y, fma(xb[k].y, bA[k].x, s[0][k].y)));
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                s[1][k] = make_double2(fma(xb[k].x, bB[k].x, fma(-xb[k].y, bB[k].y, s[1][k].x)),
-                                       fma(xb[k].x, bB[k].y, fma(xb[k].y, bB[k].x, s[1][k].y)));
-        };
         decompose(pb0);
         IEACHE_STAMP(0)
-        if (PAIR && L >= 2) {
-            digit_row_pair(32 - BGBIT, bki, std::true_type{});
-#pragma unroll 1
-            for (int row = 2; row < L; row++) digit_row(32 - (row + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
-            decompose(pb0 + 4096u);
-            digit_row_pair(32 - BGBIT, bki + L * kRowBytes, std::false_type{});
-#pragma unroll 1
-            for (int row = L + 2; row < 2 * L; row++) digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
-        } else {
         digit_row(32 - BGBIT, bki, std::true_type{});
 #pragma unroll 1
         for (int row = 1; row < L; row++) digit_row(32 - (row + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
@@ -464,7 +413,6 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
         IEACHE_STAMP(0)
 #pragma unroll 1
         for (int row = L; row < 2 * L; row++) digit_row(32 - (row - L + 1) * BGBIT, bki + row * kRowBytes, std::false_type{});
-        }
         fft512_inverse_pair<true>(s[0], s[1], sT, lane, R);
         IEACHE_STAMP(4)
 #pragma unroll
@@ -1360,7 +1308,7 @@ bool variant_known(int32_t v) {
     switch (v) {
         case 0: case kVariantTwoWavesLds: case kVariantWide: case kVariantWide + 1: case kVariantExactOneWave:
         case kVariantWideOneLimb:
-        case kVariantOneLimbDefault: case kVariantOneLimbDefault + 1: case kVariantOneLimbDefault + 2: case kVariantOneLimbDefault + 4: case kVariantOneLimbStamps:
+        case kVariantOneLimbDefault: case kVariantOneLimbDefault + 1: case kVariantOneLimbDefault + 4: case kVariantOneLimbStamps:
         case kVariantOneLimbTwoWaves: case kVariantOneLimbTwoWaves + 1:
         case kVariantWideHandoverOneLimb: case kVariantWideHandoverOneLimb + 1:
         case kVariantOneLimbFourWaves: case kVariantOneLimbFourWaves + 1:
@@ -1473,10 +1421,6 @@ static void launch_slice(int variant, int64_t items, hipStream_t stream, const D
         case kVariantOneLimbDefault + 4:  // ... no guard arithmetic (measurement)
             IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 0>), lds_w1)
             hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, 0>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf1, st_bara, nb, st_acc, items, i0, i1, e, guard, gtw, nodiag);
-            break;
-        case kVariantOneLimbDefault + 2:  // ... the first two rows of each polynomial as an interleaved pair of forward transforms (round 4 A/B)
-            IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 2, false, true>), lds_w1)
-            hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, 2, false, true>), per4, dim3(64 * kW1Gates), lds_w1, stream, K, bkf1, st_bara, nb, st_acc, items, i0, i1, e, guard, gtw, nodiag);
             break;
         case kVariantOneLimbStamps:  // ... with phase stamps
             IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 2, true>), lds_w1)

@@ -363,54 +363,6 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
     dft8<false>(x);                          // over p0 -> k2 ; lane = 8*k0 + k1
 }
 
-// Two forward transforms interleaved in one instruction stream through ONE tile (the scheme of fft512_inverse_pair): with the
-// lane-high transposes cross-lane a forward transform has one LDS round trip, and here each one's is in flight under the other's
-// butterflies.  MID: called once both second-pass outputs exist and the twiddle registers are free.
-template <bool WSYNC, class MID = NoHook>
-__device__ __forceinline__ void fft512_forward_pair(double2 (&x)[8], double2 (&y)[8], double2* sT, int lane, const LaneRoots& R, MID mid = MID()) {
-    const int hi = lane >> 3, lo = lane & 7;
-    const int blk = hi * 72 + lo, rd = hi * 72 + lo * 9;
-    double2 tA[8], tB[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) tA[k] = R.a(k);
-    dft8_twist_fwd(x);
-    dft8_twist_fwd(y);
-#pragma unroll
-    for (int k = 0; k < 8; k++) x[k] = cmulx<false>(x[k], tA[k]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) y[k] = cmulx<false>(y[k], tA[k]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = 1; k < 8; k++) tB[k] = R.b(k);
-    xlane_hi(x);
-    dft8<false>(x);
-#pragma unroll
-    for (int k = 1; k < 8; k++) x[k] = cmulx<false>(x[k], tB[k]);
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) sT[blk + 9 * k1] = x[k1];
-    tile_sync<WSYNC>();
-#pragma unroll
-    for (int q = 0; q < 8; q++) x[q] = sT[rd + q];                 // x's round trip in flight ...
-    xlane_hi(y);
-    dft8<false>(y);                                                 // ... under y's second pass
-#pragma unroll
-    for (int k = 1; k < 8; k++) y[k] = cmulx<false>(y[k], tB[k]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!std::is_same<MID, NoHook>::value) {
-        mid();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) sT[blk + 9 * k1] = y[k1];       // issued after x's reads: in-order LDS keeps them apart
-    tile_sync<WSYNC>();
-#pragma unroll
-    for (int q = 0; q < 8; q++) y[q] = sT[rd + q];                 // y's round trip ...
-    dft8<false>(x);                                                 // ... under x's last pass
-    __builtin_amdgcn_sched_barrier(0);
-    dft8<false>(y);
-    tile_sync<WSYNC>();
-}
-
 // Inverse of fft512_forward (unnormalised: 512 x), also removing the lane part of the twist:
 //   in : spectrum in the layout fft512_forward produces
 //   out: x[r] * untwist_gain(r) = y_{64r+lane}: untwisted and normalised up to one real factor per register, which the
