@@ -1155,6 +1155,18 @@ def test_old_libtfhe_parameter_set_on_fast_kernel(ia, gpu_ctx):
         assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), out), variant
     ctx.set_option("br_variant", 0)
     ctx.set_option("br_wide_max", 256)
+    # a wide launch of this set takes the two-limb one-wave-per-gate kernel (k_blind_rotate_x1<2,10>): against the oracle on
+    # sampled gates and against the two-waves-per-gate kernel on all of them (ragged last workgroup)
+    wide_bits = np.random.default_rng(210).integers(0, 2, size=(2, 1101)).astype(np.uint8)
+    wa, wb = kb.enc(wide_bits[0], 64), kb.enc(wide_bits[1], 65)
+    assert ctx.kernel_for_launch(1101) == "k_blind_rotate_x1<2,10>"
+    wout = ctx.gates(ia.GATE_AND, wa, wb)
+    assert np.array_equal(kb.dec(wout), wide_bits[0] & wide_bits[1])
+    for i in (0, 517, 1100):
+        assert np.array_equal(kb.ck.gate("and", wa[i], wb[i]), wout[i]), i
+    ctx.set_option("exact_one_wave_min", 1 << 40)
+    assert ctx.kernel_for_launch(1101) == "k_blind_rotate_w2<2,10>" and np.array_equal(ctx.gates(ia.GATE_AND, wa, wb), wout)
+    ctx.set_option("exact_one_wave_min", 1025)
     x = kb.enc([1, 0, 1], 63)
     acc = ctx.debug_blind_rotate(x, 3)
     for i in range(3):
