@@ -24,6 +24,8 @@ def test_algorithmic_model_matches_the_survey(bench, ia):
     assert bench.algorithmic_flops_per_gate(p) == 630 * (8 * 5 * 512 * 9 + 12 * 512 * 8) == 630 * 233472
     bk, ksk, io = bench.algorithmic_bytes(p)
     assert (bk, int(ksk), io) == (30965760, 15507456, 7572) and bk + int(ksk) + io == 46480788
+    # the provably exact two-limb product (the `exact` leg): forward transforms shared, inverse transforms and MACs doubled
+    assert bench.algorithmic_flops_per_gate(p, limbs=2) == 630 * (10 * 5 * 512 * 9 + 24 * 512 * 8) == 630 * 328704
 
 
 def test_roofline_record_from_synthetic_stats(bench, ia):
@@ -55,6 +57,10 @@ def test_roofline_record_from_synthetic_stats(bench, ia):
     rk = bench.roofline(p, st2, 1e5, pmc, "k_blind_rotate_w2r<3,7>")
     assert rk["kernel"] == "k_blind_rotate_w2r<3,7>" and "valu_issue" not in rk and rk["traffic"] is None and "pmc_note" in rk
     assert bench.roofline(p, st, 8192 / 40.8e-3, pmc, pmc["kernel"].split("<")[0] + "<3,7>")["valu_issue"]
+    # the exact leg's record prices the two-limb product's flops on the same launch times
+    rx = bench.roofline(p, st, 8192 / 40.8e-3, None, "k_blind_rotate_x1<3,7>", limbs=2)
+    assert rx["algorithmic_flops_per_gate"] == 630 * 328704 and abs(rx["frac"] / r["frac"] - 328704 / 233472) < 1e-12
+    assert "10 transforms" in rx["note"] and "24 M complex MACs" in rx["note"]
     # without committed counters the record still carries the algorithmic fraction
     r0 = bench.roofline(p, st, 8192 / 40.8e-3, None)
     assert r0["frac"] == r["frac"] and "valu_issue" not in r0 and r0["traffic"] is None
