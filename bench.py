@@ -314,11 +314,10 @@ def progress(rank, msg):
         print("[bench %6.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
-def count_gpus_without_runtime():
+def count_gpus_without_runtime(base="/sys/class/kfd/kfd/topology/nodes"):
     """GPUs of this node as the kernel driver lists them (KFD topology: nodes with SIMDs), narrowed by HIP_/ROCR_VISIBLE_DEVICES;
     None when sysfs does not say (the ranks then report a shortage themselves)."""
     try:
-        base = "/sys/class/kfd/kfd/topology/nodes"
         n = 0
         for node in os.listdir(base):
             props = dict(l.split()[:2] for l in open(os.path.join(base, node, "properties")) if len(l.split()) >= 2)

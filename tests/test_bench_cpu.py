@@ -99,3 +99,18 @@ def test_self_launch_builds_a_torchrun_command_and_relays(bench, monkeypatch, ca
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3"])
     monkeypatch.setattr(bench, "count_gpus_without_runtime", lambda: None)
     assert bench.self_launch(types.SimpleNamespace(gpus=3, backend="nccl")) == 7 and seen["cmd"][1:3] == ["-m", "torch.distributed.run"]
+
+
+def test_launcher_counts_gpus_from_the_kfd_topology(bench, tmp_path, monkeypatch):
+    """The launcher's GPU count comes from sysfs (nodes with SIMDs are GPUs, the CPU node has none), narrowed by the
+    visible-devices variables; no HIP call."""
+    for node, simds in (("0", 0), ("1", 1024), ("2", 1024), ("3", 1024)):
+        d = tmp_path / node
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simds == 0 else 0, simds))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.count_gpus_without_runtime(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus_without_runtime(str(tmp_path)) == 2
+    assert bench.count_gpus_without_runtime(str(tmp_path / "missing")) is None
