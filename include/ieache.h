@@ -176,7 +176,7 @@ int ieache_ctx_set_chunk(ieache_ctx* ctx, int64_t gate_instances_per_launch);
 int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
 /* named knobs: "chunk", "force_generic", "ks_mfma_min" (launches of at least this many gate instances key-switch as an
  * int8 product on the MFMA pipe; default 64), "ks_mfma_split", "ks_sliced_min", "ks_gates", "ks_slice", "ks_batch_min",
- * "br_slice", "br_wide_max", "br_variant", "exact_fft", "fft_audit", "one_limb_min", "four_wave_max", "two_wave_max", "ks_split_max"
+ * "br_slice", "br_wide_max", "br_variant" (0 or a number of csrc/blind_rotate_w64.h's table), "exact_fft", "exact_one_wave_min", "fft_audit", "one_limb_min", "four_wave_max", "two_wave_max", "ks_split_max"
  * (see csrc/evaluator.h), and
  * "level_quantum" (0/1, default 1: the slack-balanced circuits -- 64/128-bit multipliers -- get a level
  * width that makes level x batch a whole number of resident-workgroup rounds; same DAG and output bits, more
