@@ -763,6 +763,13 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert 0 < dev < 1 / 16 and reruns == 0                # rounding stayed far from the 0.5 that would flip a bit
     ctx.set_option("exact_fft", 1)                         # two-limb (provably exact) kernel for every launch size
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
+    # ... which kernel by launch size: 2L waves per gate up to one per CU, two waves per gate up to four per CU, one wave per
+    # gate above ("exact_one_wave_min" moves that boundary)
+    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (200, 300, 1024, 1025)] == \
+        ["k_blind_rotate_wide", "k_blind_rotate_w2", "k_blind_rotate_w2", "k_blind_rotate_x1"]
+    ctx.set_option("exact_one_wave_min", 0)
+    assert ctx.kernel_for_launch(300).startswith("k_blind_rotate_x1") and np.array_equal(ctx.gates(ia.GATE_AND, a[:300], b[:300]), ref[:300])
+    ctx.set_option("exact_one_wave_min", 1025)
     ctx.set_option("exact_fft", 0)
     ctx.set_option("fft_guard_inject", 1)                  # a tripped guard makes the call repeat itself on the two-limb kernel
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
@@ -862,6 +869,13 @@ def test_edge_cases_empty_batch_and_chunking(ia, gpu_ctx):
     vals = [(0xFFFFFFFF, 0xFFFFFFFF), (0, 0), (1, 0xFFFFFFFF), (0x80000000, 0x80000000), (12345, 67890)]
     inp = _inputs(kb, 2, 32, vals, 17)
     ref = ctx.eval_batch(ia.CIRC_SUB, 32, inp)
+    # ieache_prepare_batch: allocations ahead of an evaluation -- idempotent, for a batch larger and smaller than the last one, an
+    # empty batch, an unknown circuit refused; the evaluation after it produces the same bits
+    for b in (len(vals), 64, 0, len(vals)):
+        ctx.prepare(ia.CIRC_SUB, 32, b)
+    with pytest.raises(ia.IeacheError):
+        ctx.prepare(99, 32, 4)
+    assert np.array_equal(ctx.eval_batch(ia.CIRC_SUB, 32, inp), ref)
     ctx.set_chunk(7)  # every level split into ragged chunks
     st = ia.Stats()
     assert np.array_equal(ctx.eval_batch(ia.CIRC_SUB, 32, inp, st), ref)
