@@ -469,7 +469,8 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
 // spectrum sums s[2 c + limb] (128 VGPRs), four inverse transforms (two interleaved pairs through the gate's one tile),
 // the two limbs of an output recombined as lo + (hi << 16) mod 2^32.  With the sums taking half the register file, only two
 // BK blocks are in flight at a time: block 0 of a row is requested inside its forward transform (once the second twiddle
-// set is consumed), block q + 2 when block q has been multiplied.  No guard: nothing here can round wrongly.
+// set is consumed), block q + 2 when block q has been multiplied; the second decomposition's addresses and sign masks are
+// recomputed rather than kept from the first (46 registers).  No guard: nothing here can round wrongly.
 // dynamic LDS as k_blind_rotate_w1b: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2   (78 848 B -> 2 per CU)
 template <int L, int BGBIT>
 __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K, const double2* __restrict__ bkf,
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K,
             }
             __builtin_amdgcn_sched_barrier(0);
             auto req = [&]() { load_bk_block(bA, bk_rsrc, lane16, brow); };  // block 0: output 0, low limb
-            fft512_forward<true, 1, decltype(req), true, true>(x, sT, lane, R, req);
+            fft512_forward<true, 1, decltype(req), true>(x, sT, lane, R, req);
             load_bk_block(bB, bk_rsrc, lane16, brow + kBlockBytes);          // block 1: output 0, high limb
             __builtin_amdgcn_sched_barrier(0);
             // block q + 2 is requested when block q has been multiplied (re-requesting register by register, right behind the

@@ -309,12 +309,10 @@ constexpr int kTile = 8 * 72;  // double2 elements per tile (9216 B)
 // XLANE = 1: the first (lane-high) transpose cross-lane (v_permlane*_swap / v_cndmask_b32_dpp) instead of through the tile.
 // MID: called once the first inter-pass twiddles are consumed (their 32 VGPRs are free from there on) or, MID_LATE, once
 // the second set is consumed too: the place to request data the caller needs right after the transform.
-// TBF: keep the second twiddle set's loads behind the first set's multiplies (a scheduling fence): the compiler otherwise
-// hoists them, and a caller that holds 128 registers of spectrum sums (k_blind_rotate_x1) cannot afford both sets live at once.
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-template <bool WSYNC, int XLANE = 0, class MID = NoHook, bool MID_LATE = false, bool TBF = false>
+template <bool WSYNC, int XLANE = 0, class MID = NoHook, bool MID_LATE = false>
 __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int lane, const LaneRoots& R, MID mid = MID()) {
     static_assert(XLANE == 0 || XLANE == 1, "lane-low transposes go through the tile");
     const int hi = lane >> 3, lo = lane & 7;
@@ -332,7 +330,6 @@ __device__ __forceinline__ void fft512_forward(double2 (&x)[8], double2* sT, int
         mid();
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (TBF) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 1; k < 8; k++) tB[k] = R.b(k);
     if (XLANE) {
