@@ -3,6 +3,8 @@
 Statistics are SURVEY.md App. C (replayed from Cloud/cloud.c); plaintext
 semantics are pinned by integer arithmetic and the reference's canned operands
 (Client1/process.c:94-99,122-129,152-163,185-204: value = 2^(bits-2))."""
+import os
+
 import numpy as np
 import pytest
 
@@ -250,3 +252,17 @@ def test_kogge_stone_adders_plaintext(ia, bits):
     if bits >= 16:
         ks, rc = ia.circuit_info(ia.CIRC_ADD_KS, bits), ia.circuit_info(ia.CIRC_ADD, bits)
         assert ks.depth < rc.depth // 3 and ks.n_and + ks.n_xor == ks.bootstraps  # only the reference's gate types
+
+
+def test_twisted_radix8_passes_match_their_defining_sums(tmp_path):
+    """The radix-8 passes that carry the register part of the negacyclic twist (csrc/dft8_twist.h, compiled into every
+    blind-rotation kernel through fft512.h) are plain arithmetic: on the host they must equal the sums they stand for --
+    X_k = sum_r y_r e^{i pi r/16} W8^{rk} forward, its conjugate transpose with the pending real gains inverse."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "dft8_twist_test"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "ie-ache_amd", "csrc"),
+                           os.path.join(root, "tests", "native", "dft8_twist_test.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "forward" in r.stdout and "inverse" in r.stdout
