@@ -41,6 +41,11 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+// coefficients of B fragments in flight per wave: 8 (round 4; 4 until then: 0.658 -> 0.610 ms per 8 192 gates, profiles/r4_keyswitch_ahead.txt).
+// 4 or 8: the walk of a K split is a multiple of 8 coefficients for every supported N (N % 64 == 0, splits <= 8).
+#ifndef IEACHE_KS_AHEAD
+#define IEACHE_KS_AHEAD 8
+#endif
 constexpr int kWaveGates = 128;   // four 32-row tiles
 constexpr int kWgWaves = 4;
 constexpr int kWgGates = kWaveGates * kWgWaves;
@@ -148,35 +153,42 @@ __global__ __launch_bounds__(64 * kWgWaves) void k_ksm_gemm(const v4i* __restric
     unsigned long long d64[4], d64n[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) d64n[t] = dg[(size_t)i4_0 * gpad + t * 32];
-    // B fragments are requested FOUR coefficients ahead (one wave per SIMD has nothing else to hide an L2 miss behind):
-    // buffer c holds coefficient 4 i4 + c and is refilled with 4 (i4 + 1) + c right after its products are issued
-    v4i bq[4][4];
+    // B fragments are requested kAhead coefficients ahead (one wave per SIMD has nothing else to hide an L2 miss behind):
+    // buffer c holds coefficient 4 i4 + c (kAhead = 8: of two consecutive i4) and is refilled with the coefficient kAhead further
+    // on right after its products are issued
+    constexpr int kAhead = IEACHE_KS_AHEAD;   // 4 or 8
+    constexpr int kGroups = kAhead / 4;       // i4 values per trip of the loop
+    v4i bq[kAhead][4];
     const v4i* bp0 = limbs + (size_t)cb * 256 + lane;
 #pragma unroll
-    for (int c = 0; c < 4; c++)
+    for (int c = 0; c < kAhead; c++)
 #pragma unroll
         for (int l = 0; l < 4; l++) bq[c][l] = bp0[(size_t)(4 * i4_0 + c) * ncb * 256 + l * 64];
 #pragma unroll 1
-    for (int32_t i4 = i4_0; i4 < i4_1; i4++) {
+    for (int32_t i4 = i4_0; i4 < i4_1; i4 += kGroups) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) d64[t] = d64n[t];
-        const bool more = i4 + 1 < i4_1;
-        if (more) {
+        for (int gq = 0; gq < kGroups; gq++) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) d64n[t] = dg[(size_t)(i4 + 1) * gpad + t * 32];
-        }
+            for (int t = 0; t < 4; t++) d64[t] = d64n[t];
+            const bool more_d = i4 + gq + 1 < i4_1;
+            if (more_d) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            v4i a[4];
+                for (int t = 0; t < 4; t++) d64n[t] = dg[(size_t)(i4 + gq + 1) * gpad + t * 32];
+            }
+            const bool more = i4 + gq + kGroups < i4_1;
 #pragma unroll
-            for (int t = 0; t < 4; t++) a[t] = lut[(unsigned)(d64[t] >> (16 * c + sh0)) & 0xFFu];
+            for (int c = 0; c < 4; c++) {
+                v4i a[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+                for (int t = 0; t < 4; t++) a[t] = lut[(unsigned)(d64[t] >> (16 * c + sh0)) & 0xFFu];
 #pragma unroll
-                for (int l = 0; l < 4; l++) acc[t][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t], bq[c][l], acc[t][l], 0, 0, 0);
-            if (more) {
+                for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int l = 0; l < 4; l++) bq[c][l] = bp0[(size_t)(4 * (i4 + 1) + c) * ncb * 256 + l * 64];
+                    for (int l = 0; l < 4; l++) acc[t][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[t], bq[4 * gq + c][l], acc[t][l], 0, 0, 0);
+                if (more) {
+#pragma unroll
+                    for (int l = 0; l < 4; l++) bq[4 * gq + c][l] = bp0[(size_t)(4 * (i4 + gq + kGroups) + c) * ncb * 256 + l * 64];
+                }
             }
         }
     }
