@@ -599,12 +599,17 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide1(DevKeys K, const
     }
 }
 
+// ---- round 4: k_blind_rotate_wide12 (12 waves per gate, even / odd half transforms of four points per lane) ----
+#include "wide12.h"
+
 }  // namespace
 
 // code-generation check (make attic): one instantiation of each
-extern const void* const attic_kernels[4];
-const void* const attic_kernels[4] = {(const void*)k_blind_rotate_w1<3, 7, true>, (const void*)k_blind_rotate_w2s<3, 7, true>,
-                                     (const void*)k_blind_rotate_wide4b<3, 7, 2>, (const void*)k_blind_rotate_wide1<3, 7, true>};
+extern const void* const attic_kernels[7];
+const void* const attic_kernels[7] = {(const void*)k_blind_rotate_w1<3, 7, true>, (const void*)k_blind_rotate_w2s<3, 7, true>,
+                                     (const void*)k_blind_rotate_wide4b<3, 7, 2>, (const void*)k_blind_rotate_wide1<3, 7, true>,
+                                     (const void*)k_blind_rotate_wide12<3, 7, 2>, (const void*)k_blind_rotate_wide12<2, 10, 2>,
+                                     (const void*)k_bk_to_spectrum_w12};
 
 }  // namespace w64
 }  // namespace ieache

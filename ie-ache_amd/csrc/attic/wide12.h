@@ -10,11 +10,12 @@
 // transposes cross-lane: v_permlane32/16_swap, v_cndmask_b32_dpp).  Forward phase: 4L waves, one per (digit row, parity) --
 // three per SIMD, each with half of wide4's decomposition and a transform of a third of its instructions.  Output phase:
 // eight waves, one per (output polynomial c, row half, output parity): 2L point-wise products with the key's half spectra
-// (KA, KB and Y KB, precomputed: k_bk_to_spectrum_w12), ONE 256-point inverse, rounding, ds_add_u32 into the accumulator --
+// (KA and KB, precomputed: k_bk_to_spectrum_w12; BK_i is copied into LDS by LDS-DMA at the top of the step), ONE 256-point inverse, rounding, ds_add_u32 into the accumulator --
 // every partial sum is an integer polynomial, so the two row halves of an output need no ordering (as in wide4).
 // Two workgroup barriers per step.  Same rounded integers as every other kernel (tests: variants 40 / 41).
-// scripts/model/wide12_model.py states the index maps in numpy and checks them against the negacyclic product.
-// Included by blind_rotate_w64.hip inside namespace ieache::w64::{anonymous}, after the kernels it shares helpers with.
+// wide12_model.py (this directory) states the index maps in numpy and checks them against the negacyclic product.
+// ATTIC (measured and lost: profiles/r4_narrow_ab.txt).  Included by blind_rotate_attic.hip inside namespace ieache::w64::{anonymous};
+// in the product build of commit 3e9995d it was included by blind_rotate_w64.hip the same way, with br_variant 40 / 41 / 42.
 #pragma once
 
 constexpr int kQ = 256;  // points of a half transform

@@ -26,16 +26,12 @@ size_t state_bytes_per_item(const Params& p);
 // Returns the number of k_blind_rotate_w2 launches issued.
 // d_bkf1 / guard: the one-limb spectrum and the two-word guard record of k_blind_rotate_w1 (may be null for the
 // two-limb variants).
-// d_bkw: the half spectra of k_blind_rotate_wide12 (variants 40 / 41; may be null for every other variant).
-int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const double2* d_bkf1, const double2* d_bkw, unsigned* guard,
+int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard,
            const dev::WorkDesc& W, int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice,
            int32_t variant, const double2* d_twiddles, hipStream_t stream);
 // one-limb form (k_blind_rotate_w1): raw BK -> spectrum [n][2l][2][8][64] double2
 size_t spectrum1_elems(const Params& p);
 void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1, hipStream_t stream);
-// k_blind_rotate_wide12's form: raw BK -> even / odd half spectra [n][2l][2][KA, KB, Y KB][4][64] double2
-size_t spectrum12_elems(const Params& p);
-void prepare_spectrum12(const Params& p, const Torus32* d_bk_raw, double2* d_bkw, hipStream_t stream);
 size_t lds_bytes_w1();
 int gates_per_workgroup_w1();
 // the kernels' twiddle table (twiddle_table_elems() double2 in device memory), built once per context
@@ -53,7 +49,6 @@ void build_twiddle_table(double2* d_tw, hipStream_t stream);
 //     36 k_blind_rotate_w2r: two waves per gate, rows split (2 .. 5 gates per CU)      37 guard on every coefficient
 //     43 k_blind_rotate_w4r: four waves per gate, rows 2:1:2:1 (1 .. 2 gates per CU)  44 guard on every coefficient
 //     38 k_blind_rotate_wide4: 2L waves per gate, four output waves (<= 1 gate per CU) 39 guard on every coefficient
-//     40 k_blind_rotate_wide12: 4L waves per gate, even / odd half transforms of 4 points per lane (round 4)   41 guard on every coefficient
 //     24 k_blind_rotate_wide on the one-limb spectrum (round 2's latency kernel, the A/B partner of 38)
 // Every other number of rounds 1-3 (k_blind_rotate_w1, _w2s, _wide1, _wide4b and the template flags that lost their A/B) is
 // refused; attic/README.md maps them to the profile that records each measurement.
@@ -69,7 +64,6 @@ constexpr int32_t kVariantOneLimbStamps = 49;
 constexpr int32_t kVariantOneLimbTwoWaves = 36;     // k_blind_rotate_w2r (round 3)
 constexpr int32_t kVariantOneLimbFourWaves = 43;    // k_blind_rotate_w4r (round 3): launches of one to two gates per CU
 constexpr int32_t kVariantWideHandoverOneLimb = 38;  // k_blind_rotate_wide4 (round 3)
-constexpr int32_t kVariantTwelveWaves = 40;          // k_blind_rotate_wide12 (round 4)
 
 }  // namespace w64
 }  // namespace ieache

@@ -1125,13 +1125,14 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide(DevKeys K, const 
 // polynomial to ONE wave (two output waves; the other four idle for half of the step), and its tiles serve both as the
 // published spectra and as the inverse transforms' scratch (barrier B).  Here waves 0..3 are output waves (one per SIMD):
 // output wave (c, h) = (w & 1, w >> 1) multiplies the L published spectra of accumulator polynomial h with block c of
-// their BK rows -- its L blocks are requested at the top of the step and arrive under the decomposition and the forward
-// transform --, inverse-transforms that PARTIAL sum in a scratch tile of its own (no barrier B), rounds it and adds it
+// their BK rows -- its L blocks are requested one row at a time across the forward phase (at the top of the step, behind the
+// decomposition's LDS reads, inside the forward transform: a wave that queues all 24 requests first starts its forward work
+// that much later; -3 ... -6 % per rotation, profiles/r4_narrow_ab.txt) and arrive under the forward transform --, inverse-transforms that PARTIAL sum in a scratch tile of its own (no barrier B), rounds it and adds it
 // into accumulator polynomial c with ds_add_u32.  Each partial sum is an integer polynomial and addition mod 2^32
 // commutes, so the two halves of an output need no ordering.  Two barriers per step (spectra published / accumulator
 // updated).  Same rounded integers as every other kernel here.
 // dynamic LDS: acc [2][1024] int32 | sT [2L + 4][kTile] double2 | tw [kTwElems] double2 | bara [i1-i0] u16
-template <int L, int BGBIT, int GUARD, bool SPREAD = false>
+template <int L, int BGBIT, int GUARD>
 __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const double2* __restrict__ bkf1,
                                                               const uint16_t* __restrict__ st_bara, int32_t nb,
                                                               int32_t* st_acc, int32_t i0, int32_t i1, Torus32* ext,
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
     for (int32_t i = i0; i < i1; i++) {
         const int32_t a = __builtin_amdgcn_readfirstlane((int32_t)s_bara[i - i0]);
         if (a == 0) continue;  // workgroup-uniform
-        // BK_i rows [2L][2][8][64]: this output wave's L blocks, all requested now
+        // BK_i rows [2L][2][8][64]: this output wave's L blocks, one row per request point
         const double2* __restrict__ bki = bkf1 + (size_t)i * (2 * L * 2 * kM) + (size_t)(oh * L) * (2 * kM) + (size_t)oc * kM + lane;
         double2 bk[L][8];
         auto request = [&](int q) {
@@ -1187,10 +1188,6 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
             }
         };
         request(0);
-        if (!SPREAD) {
-#pragma unroll
-            for (int q = 1; q < L; q++) request(q);
-        }
         __builtin_amdgcn_sched_barrier(0);
         int32_t lane_o = lane;
         asm volatile("" : "+v"(lane_o));  // opaque: keeps the per-coefficient LDS addresses from being hoisted out of the step loop
@@ -1206,10 +1203,8 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
             pv1[r] = (uint32_t)accp[64 * r + lane_o + kM];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (SPREAD) {
-            request(1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        request(1);
+        __builtin_amdgcn_sched_barrier(0);
         double2 x[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -1222,7 +1217,7 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
             const int32_t e1 = __builtin_amdgcn_sbfe((int32_t)(u1 ^ (halfBg << sh)), sh, BGBIT);
             x[r] = make_double2((double)e0, (double)e1);  // untwisted: the first radix-8 pass applies e^{i pi r/16} itself
         }
-        if (SPREAD && L > 2)
+        if (L > 2)
             fft512_forward<true, 0>(x, sT, lane, R, [&]() {
 #pragma unroll
                 for (int q = 2; q < L; q++) request(q);
@@ -1277,8 +1272,6 @@ __global__ __launch_bounds__(128 * L) void k_blind_rotate_wide4(DevKeys K, const
     }
 }
 
-#include "wide12.h"  // k_blind_rotate_wide12: 4L waves per gate
-
 }  // namespace
 
 // N=1024, k=1 with either libtfhe parameter set: l=3/Bgbit=7 (>= v1.1, "128-bit") or l=2/Bgbit=10
@@ -1294,7 +1287,6 @@ bool one_limb_supported(const Params& p) { return supported(p) && p.l == 3 && p.
 
 size_t spectrum_elems(const Params& p) { return (size_t)p.n * p.kpl() * 4 * kM; }
 size_t spectrum1_elems(const Params& p) { return (size_t)p.n * p.kpl() * 2 * kM; }
-size_t spectrum12_elems(const Params& p) { return (size_t)p.n * p.kpl() * 2 * 2 * kQ; }
 size_t lds_bytes_w1() { return (size_t)(kW1Gates * kTile + kTwElems) * sizeof(double2) + (size_t)kW1Gates * 2 * kN * 4; }
 int gates_per_workgroup_w1() { return kW1Gates; }
 
@@ -1323,11 +1315,6 @@ void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1
     hipLaunchKernelGGL(k_bk_to_spectrum_w64_1, dim3((unsigned)npoly), dim3(64), 0, stream, d_bk_raw, d_bkf1);
 }
 
-void prepare_spectrum12(const Params& p, const Torus32* d_bk_raw, double2* d_bkw, hipStream_t stream) {
-    const size_t npoly = (size_t)p.n * p.kpl() * 2;
-    hipLaunchKernelGGL(k_bk_to_spectrum_w12, dim3((unsigned)npoly), dim3(64), 0, stream, d_bk_raw, d_bkw);
-}
-
 bool variant_known(int32_t v) {
     switch (v) {
         case 0: case kVariantTwoWavesLds: case kVariantWide: case kVariantWide + 1: case kVariantExactOneWave:
@@ -1336,7 +1323,6 @@ bool variant_known(int32_t v) {
         case kVariantOneLimbTwoWaves: case kVariantOneLimbTwoWaves + 1:
         case kVariantWideHandoverOneLimb: case kVariantWideHandoverOneLimb + 1:
         case kVariantOneLimbFourWaves: case kVariantOneLimbFourWaves + 1:
-        case kVariantTwelveWaves: case kVariantTwelveWaves + 1: case kVariantTwelveWaves + 2: case 45: case 46:
             return true;
         default: return false;
     }
@@ -1346,7 +1332,7 @@ bool variant_one_limb(int32_t v) { return variant_known(v) && v >= kVariantWideO
 static bool variant_long_slices(int32_t v) {
     return v == kVariantWide || v == kVariantWide + 1 || v == kVariantWideOneLimb || v == kVariantOneLimbTwoWaves ||
            v == kVariantOneLimbTwoWaves + 1 || v == kVariantWideHandoverOneLimb || v == kVariantWideHandoverOneLimb + 1 ||
-           v == kVariantOneLimbFourWaves || v == kVariantOneLimbFourWaves + 1 || v == kVariantTwelveWaves || v == kVariantTwelveWaves + 1 || v == kVariantTwelveWaves + 2 || v == 45 || v == 46;
+           v == kVariantOneLimbFourWaves || v == kVariantOneLimbFourWaves + 1;
 }
 
 static int32_t device_cus() {
@@ -1401,14 +1387,13 @@ static int32_t w4r_flip_period() {
 // one slice [i0, i1) of CMux steps for `items` gate instances on the kernel `variant` names
 template <int L, int BGBIT>
 static void launch_slice(int variant, int64_t items, hipStream_t stream, const DevKeys& K, const double2* bkf2, const double2* bkf1,
-                         const double2* bkw, const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e, unsigned* guard,
+                         const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e, unsigned* guard,
                          const double2* gtw) {
     const dim3 per_gate((unsigned)items), per4((unsigned)((items + kW1Gates - 1) / kW1Gates));
     const size_t lds_w1 = lds_bytes_w1();
     const size_t lds_w2 = (size_t)(2 * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
     const size_t lds_w4 = (size_t)(4 * kTile + 2 * 8 * 64 + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
     const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
-    const size_t lds_w12 = (size_t)(4 * L * kQ + 2 * L * 2 * 2 * kQ) * sizeof(double2) + (size_t)2 * kN * 4 + 256 + (size_t)nb * 2;
     const size_t lds_wide4 = (size_t)((2 * L + 4) * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
     unsigned long long* const nodiag = nullptr;
     switch (variant) {
@@ -1474,26 +1459,6 @@ static void launch_slice(int variant, int64_t items, hipStream_t stream, const D
             IEACHE_ALLOW_LDS((k_blind_rotate_wide4<L, BGBIT, 1>), 160 * 1024)
             hipLaunchKernelGGL((k_blind_rotate_wide4<L, BGBIT, 1>), per_gate, dim3(128 * L), lds_wide4, stream, K, bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
             break;
-        case 45:  // k_blind_rotate_wide4 with its BK requests spread over the forward phase (A/B)
-            IEACHE_ALLOW_LDS((k_blind_rotate_wide4<L, BGBIT, 2, true>), 160 * 1024)
-            hipLaunchKernelGGL((k_blind_rotate_wide4<L, BGBIT, 2, true>), per_gate, dim3(128 * L), lds_wide4, stream, K, bkf1, st_bara, nb, st_acc, i0, i1, e, guard, gtw);
-            break;
-        case 46:  // k_blind_rotate_wide12 without the L2 prefetch of the next step's BK block (A/B)
-            IEACHE_ALLOW_LDS((k_blind_rotate_wide12<L, BGBIT, 2, false, false>), 160 * 1024)
-            hipLaunchKernelGGL((k_blind_rotate_wide12<L, BGBIT, 2, false, false>), per_gate, dim3(256 * L), lds_w12, stream, K, bkw, st_bara, nb, st_acc, i0, i1, e, guard, nodiag);
-            break;
-        case kVariantTwelveWaves:  // 4L waves per gate, half-size transforms (latency, round 4)
-            IEACHE_ALLOW_LDS((k_blind_rotate_wide12<L, BGBIT, 2>), 160 * 1024)
-            hipLaunchKernelGGL((k_blind_rotate_wide12<L, BGBIT, 2>), per_gate, dim3(256 * L), lds_w12, stream, K, bkw, st_bara, nb, st_acc, i0, i1, e, guard, nodiag);
-            break;
-        case kVariantTwelveWaves + 1:
-            IEACHE_ALLOW_LDS((k_blind_rotate_wide12<L, BGBIT, 1>), 160 * 1024)
-            hipLaunchKernelGGL((k_blind_rotate_wide12<L, BGBIT, 1>), per_gate, dim3(256 * L), lds_w12, stream, K, bkw, st_bara, nb, st_acc, i0, i1, e, guard, nodiag);
-            break;
-        case kVariantTwelveWaves + 2:  // ... with phase stamps
-            IEACHE_ALLOW_LDS((k_blind_rotate_wide12<L, BGBIT, 2, true>), 160 * 1024)
-            hipLaunchKernelGGL((k_blind_rotate_wide12<L, BGBIT, 2, true>), per_gate, dim3(256 * L), lds_w12, stream, K, bkw, st_bara, nb, st_acc, i0, i1, e, guard, diag_buf());
-            break;
         default: throw std::invalid_argument("unknown blind-rotation variant");
     }
 }
@@ -1508,12 +1473,11 @@ int32_t default_slice() {
     return s > 0 ? (s < 64 ? s : 64) : 16;  // <= 64: one rotation amount per lane
 }
 
-int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, const double2* d_bkw, unsigned* guard, const WorkDesc& W,
+int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
            const double2* d_twiddles, hipStream_t stream) {
     if (!variant_known(variant)) throw std::invalid_argument("unknown blind-rotation variant");
     if (variant_one_limb(variant) && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
-    if (((variant >= kVariantTwelveWaves && variant <= kVariantTwelveWaves + 2) || variant == 46) && !d_bkw) throw std::runtime_error("k_blind_rotate_wide12 without its half spectra");
     int launches = 0;
     const int32_t nb = bara_stride(p);
     // state block: [items][2][1024] int32 accumulators, then [items][nb] u16 rotation amounts
@@ -1525,9 +1489,9 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     auto one = [&](int v, int32_t i0, int32_t i1, Torus32* e) {
         if (p.l == 3)
-            launch_slice<3, 7>(v, items, stream, K, d_bkf, d_bkf1, d_bkw, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles);
+            launch_slice<3, 7>(v, items, stream, K, d_bkf, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles);
         else
-            launch_slice<2, 10>(v, items, stream, K, d_bkf, d_bkf1, d_bkw, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles);
+            launch_slice<2, 10>(v, items, stream, K, d_bkf, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles);
     };
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
@@ -1538,9 +1502,6 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     if (variant == kVariantOneLimbStamps) {
         static const char* names[6] = {"decomposition (x2)", "digits+cvt+twist (x6)", "forward transform (x6)", "2nd BK block + products (x6)", "inverse pair", "round+update"};
         diag_report(stream, "w1b, waves by parity", names, 6, denom / 2.0);  // each of the two slots collects half of the waves
-    } else if (variant == kVariantTwelveWaves + 2) {
-        static const char* names[8] = {"head+decompose", "fwd256", "publish", "barrier A", "products", "inv256", "round+update", "barrier C"};
-        diag_report(stream, "wide12, waves 0 / 8", names, 8, denom);
     } else if (variant == kVariantWide + 1) {
         static const char* names[8] = {"head+decompose", "fwdFFT", "publish+BK issue", "barrier A", "MAC rows", "barrier B", "invFFT+update", "barrier C"};
         diag_report(stream, "wide, waves 0 / 4", names, 8, denom);

@@ -521,7 +521,6 @@ struct Evaluator::Impl {
     double2* bkf_w64 = nullptr;  // spectrum in the wave-per-gate kernel's layout
     double2* tw_w64 = nullptr;   // its twiddle table
     double2* bkf1_w64 = nullptr; // one-limb spectrum of k_blind_rotate_w1
-    double2* bkw_w64 = nullptr;  // even / odd half spectra of k_blind_rotate_wide12
     unsigned* fft_guard = nullptr;  // [0] launches whose rounding deviation exceeded the limit, [1] max deviation (float bits), [2] audit rows that differed
     bool exact_fft = false;      // "exact_fft": never use the one-limb kernel
     bool exact_once = false;     // set while a call is repeated after a guard trip
@@ -688,7 +687,6 @@ void Evaluator::destroy() {
     (void)hipFree(d_->bkf_w64);
     (void)hipFree(d_->tw_w64);
     (void)hipFree(d_->bkf1_w64);
-    (void)hipFree(d_->bkw_w64);
     (void)hipFree(d_->fft_guard);
     (void)hipFree(d_->audit_ext);
     (void)hipFree(d_->audit_state);
@@ -833,11 +831,6 @@ void Evaluator::load_keys_device(const Torus32* d_bk, const Torus32* d_ksk) {
         }
         w64::prepare_spectrum1(p_, d_bk, d_->bkf1_w64, stream_);
         HIP_CHECK(hipGetLastError());
-        if (w64::one_limb_supported(p_)) {
-            if (!d_->bkw_w64) HIP_CHECK(hipMalloc(&d_->bkw_w64, w64::spectrum12_elems(p_) * sizeof(double2)));
-            w64::prepare_spectrum12(p_, d_bk, d_->bkw_w64, stream_);
-            HIP_CHECK(hipGetLastError());
-        }
     }
     hipLaunchKernelGGL(k_pad_rows, dim3(2048), dim3(256), 0, stream_, d_ksk, d_->ksk, (int64_t)ks_rows, p_.n + 1,
                        K.stride);
@@ -925,7 +918,6 @@ std::string Evaluator::kernel_for_launch(int64_t gates) const {
         case w64::kVariantOneLimbTwoWaves: name = "k_blind_rotate_w2r"; break;
         case w64::kVariantOneLimbFourWaves: name = "k_blind_rotate_w4r"; break;
         case w64::kVariantWideHandoverOneLimb: name = "k_blind_rotate_wide4"; break;
-        case w64::kVariantTwelveWaves: name = "k_blind_rotate_wide12"; break;
         case w64::kVariantWide: name = "k_blind_rotate_wide"; break;
         case w64::kVariantExactOneWave: name = "k_blind_rotate_x1"; break;
         case 0: name = "k_blind_rotate_w2"; break;
@@ -955,7 +947,7 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
         }
         int32_t variant, slice;
         pick_br_variant(p, d, cnt, &variant, &slice);
-        return w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->bkw_w64, d->fft_guard, w, cnt, d->br_state, ext, steps, dbg_acc, slice, variant,
+        return w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, w, cnt, d->br_state, ext, steps, dbg_acc, slice, variant,
                            d->tw_w64, stream);
     }
     else
@@ -983,7 +975,7 @@ static void maybe_audit(const Params& p, Evaluator::Impl* d, hipStream_t stream,
     if (!d->audit_state) HIP_CHECK(hipMalloc(&d->audit_state, (size_t)kAuditGates * w64::state_bytes_per_item(p)));
     WorkDesc wa = w;
     wa.item0 = w.item0 + off;
-    w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->bkw_w64, d->fft_guard, wa, m, d->audit_state, d->audit_ext, -1, nullptr, w64::bara_stride(p),
+    w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, wa, m, d->audit_state, d->audit_ext, -1, nullptr, w64::bara_stride(p),
                 w64::kVariantWide, d->tw_w64, stream);
     hipLaunchKernelGGL(k_audit_compare, dim3((unsigned)m), dim3(256), 0, stream, ext + (size_t)off * (size_t)(d->K.N + 4), d->audit_ext,
                        d->K.N, d->fft_guard + 2, d->audit_inject ? 1 : 0);

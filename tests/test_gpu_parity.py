@@ -747,9 +747,9 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:600], b[:600]), ref[:600]), sl
     ctx.set_option("br_slice", 0)
     # the one-limb kernels, each forced for this launch size: 31 / 32 / 35 k_blind_rotate_w1b (guard on one coefficient in four /
-    # on every one / none), 36 / 37 k_blind_rotate_w2r, 38 / 39 k_blind_rotate_wide4, 40 / 41 k_blind_rotate_wide12, 43 / 44 k_blind_rotate_w4r, 24 round 2's
+    # on every one / none), 36 / 37 k_blind_rotate_w2r, 38 / 39 k_blind_rotate_wide4, 43 / 44 k_blind_rotate_w4r, 24 round 2's
     # latency kernel on one limb; ragged last workgroup of 4 gates
-    for variant in (24, 31, 32, 35, 36, 37, 38, 39, 40, 41, 43, 44):
+    for variant in (24, 31, 32, 35, 36, 37, 38, 39, 43, 44):
         ctx.set_option("br_variant", variant)
         assert np.array_equal(ctx.gates(ia.GATE_AND, a[:301], b[:301]), ref[:301]), variant
     for variant in (31,):
