@@ -153,7 +153,9 @@ static void gl_intt(const gl_plan *pl, uint64_t *a)
 typedef struct {
     int32_t N, M, logM;     /* M = N/2 complex points */
     double *tw_re, *tw_im;  /* twist: exp(i*pi*j/N), j<M */
-    double *w_re, *w_im;    /* exp(-2*pi*i*j/M), j<M/2 */
+    double *w_re, *w_im;    /* per stage, contiguous: stage with half-size h keeps exp(-2*pi*i*j/(2h)), j<h, at offset h - 1
+                               (h = 1, 2, 4, ..., M/2: M - 1 entries) -- unit-stride twiddles let the compiler vectorise every
+                               stage with h >= 4; the strided table this replaces (w[j*stride]) ran at about half the speed */
 } fft_plan;
 
 static void fft_plan_init(fft_plan *pl, int32_t N)
@@ -164,16 +166,17 @@ static void fft_plan_init(fft_plan *pl, int32_t N)
     while ((1 << pl->logM) < pl->M) pl->logM++;
     pl->tw_re = (double *)malloc(sizeof(double) * pl->M);
     pl->tw_im = (double *)malloc(sizeof(double) * pl->M);
-    pl->w_re = (double *)malloc(sizeof(double) * (pl->M / 2 + 1));
-    pl->w_im = (double *)malloc(sizeof(double) * (pl->M / 2 + 1));
+    pl->w_re = (double *)malloc(sizeof(double) * (pl->M + 1));
+    pl->w_im = (double *)malloc(sizeof(double) * (pl->M + 1));
     for (int32_t j = 0; j < pl->M; j++) {
         pl->tw_re[j] = cos(M_PI * j / N);
         pl->tw_im[j] = sin(M_PI * j / N);
     }
-    for (int32_t j = 0; j < pl->M / 2; j++) {
-        pl->w_re[j] = cos(-2.0 * M_PI * j / pl->M);
-        pl->w_im[j] = sin(-2.0 * M_PI * j / pl->M);
-    }
+    for (int32_t h = 1; h < pl->M; h <<= 1)
+        for (int32_t j = 0; j < h; j++) {
+            pl->w_re[h - 1 + j] = cos(-M_PI * j / h);
+            pl->w_im[h - 1 + j] = sin(-M_PI * j / h);
+        }
 }
 static void fft_plan_free(fft_plan *pl)
 {
@@ -183,39 +186,68 @@ static void fft_plan_free(fft_plan *pl)
     free(pl->w_im);
 }
 /* forward DIF: natural in, bit-reversed out (no permutation pass) */
-static void fft_fwd(const fft_plan *pl, double *re, double *im)
+static void fft_fwd(const fft_plan *pl, double *restrict re, double *restrict im)
 {
-    int32_t M = pl->M;
-    for (int32_t half = M / 2, stride = 1; half >= 1; half >>= 1, stride <<= 1) {
+    const int32_t M = pl->M;
+    for (int32_t half = M / 2; half >= 4; half >>= 1) {
+        const double *restrict wr = pl->w_re + half - 1, *restrict wi = pl->w_im + half - 1;
         for (int32_t base = 0; base < M; base += 2 * half) {
+            double *restrict ar = re + base, *restrict ai = im + base, *restrict br = ar + half, *restrict bi = ai + half;
             for (int32_t j = 0; j < half; j++) {
-                int32_t a = base + j, b = a + half;
-                double wr = pl->w_re[j * stride], wi = pl->w_im[j * stride];
-                double ur = re[a], ui = im[a], vr = re[b], vi = im[b];
-                re[a] = ur + vr;
-                im[a] = ui + vi;
-                double dr = ur - vr, di = ui - vi;
-                re[b] = dr * wr - di * wi;
-                im[b] = dr * wi + di * wr;
+                const double ur = ar[j], ui = ai[j], vr = br[j], vi = bi[j];
+                const double dr = ur - vr, di = ui - vi;
+                ar[j] = ur + vr;
+                ai[j] = ui + vi;
+                br[j] = dr * wr[j] - di * wi[j];
+                bi[j] = dr * wi[j] + di * wr[j];
             }
         }
     }
+    /* the last two stages (half = 2, 1) as one radix-4 butterfly per four consecutive points: twiddles 1, -i */
+    for (int32_t b = 0; b + 4 <= M; b += 4) {
+        const double x0r = re[b], x0i = im[b], x1r = re[b + 1], x1i = im[b + 1], x2r = re[b + 2], x2i = im[b + 2], x3r = re[b + 3], x3i = im[b + 3];
+        const double a0r = x0r + x2r, a0i = x0i + x2i, a1r = x1r + x3r, a1i = x1i + x3i;
+        const double d0r = x0r - x2r, d0i = x0i - x2i;
+        const double d1r = x1i - x3i, d1i = -(x1r - x3r); /* (x1 - x3) * (-i) */
+        re[b] = a0r + a1r;
+        im[b] = a0i + a1i;
+        re[b + 1] = a0r - a1r;
+        im[b + 1] = a0i - a1i;
+        re[b + 2] = d0r + d1r;
+        im[b + 2] = d0i + d1i;
+        re[b + 3] = d0r - d1r;
+        im[b + 3] = d0i - d1i;
+    }
 }
 /* inverse DIT: bit-reversed in, natural out, unscaled */
-static void fft_inv(const fft_plan *pl, double *re, double *im)
+static void fft_inv(const fft_plan *pl, double *restrict re, double *restrict im)
 {
-    int32_t M = pl->M;
-    for (int32_t half = 1, stride = M / 2; half < M; half <<= 1, stride >>= 1) {
+    const int32_t M = pl->M;
+    for (int32_t b = 0; b + 4 <= M; b += 4) { /* half = 1, 2: twiddles 1, +i */
+        const double x0r = re[b], x0i = im[b], x1r = re[b + 1], x1i = im[b + 1], x2r = re[b + 2], x2i = im[b + 2], x3r = re[b + 3], x3i = im[b + 3];
+        const double a0r = x0r + x1r, a0i = x0i + x1i, a1r = x0r - x1r, a1i = x0i - x1i;
+        const double c0r = x2r + x3r, c0i = x2i + x3i;
+        const double c1r = -(x2i - x3i), c1i = x2r - x3r; /* (x2 - x3) * (+i) */
+        re[b] = a0r + c0r;
+        im[b] = a0i + c0i;
+        re[b + 2] = a0r - c0r;
+        im[b + 2] = a0i - c0i;
+        re[b + 1] = a1r + c1r;
+        im[b + 1] = a1i + c1i;
+        re[b + 3] = a1r - c1r;
+        im[b + 3] = a1i - c1i;
+    }
+    for (int32_t half = 4; half < M; half <<= 1) {
+        const double *restrict wr = pl->w_re + half - 1, *restrict wi = pl->w_im + half - 1;
         for (int32_t base = 0; base < M; base += 2 * half) {
+            double *restrict ar = re + base, *restrict ai = im + base, *restrict br = ar + half, *restrict bi = ai + half;
             for (int32_t j = 0; j < half; j++) {
-                int32_t a = base + j, b = a + half;
-                double wr = pl->w_re[j * stride], wi = -pl->w_im[j * stride];
-                double vr = re[b] * wr - im[b] * wi, vi = re[b] * wi + im[b] * wr;
-                double ur = re[a], ui = im[a];
-                re[a] = ur + vr;
-                im[a] = ui + vi;
-                re[b] = ur - vr;
-                im[b] = ui - vi;
+                const double vr = br[j] * wr[j] + bi[j] * wi[j], vi = bi[j] * wr[j] - br[j] * wi[j]; /* * conj(w) */
+                const double ur = ar[j], ui = ai[j];
+                ar[j] = ur + vr;
+                ai[j] = ui + vi;
+                br[j] = ur - vr;
+                bi[j] = ui - vi;
             }
         }
     }
