@@ -22,8 +22,6 @@ reps = int(os.environ.get("REPS", "3"))
 for c in counts:
     for name, opts in (("w2", {"br_variant": 0, "exact_one_wave_min": 1 << 40, "br_slice": 0}),
                        ("x1 (9)", {"br_variant": 9, "br_slice": 16}),
-                       ("x1 blocks (10)", {"br_variant": 10, "br_slice": 16}),
-                       ("x1 xmix (11)", {"br_variant": 11, "br_slice": 16}),
                        ("x1 (9) again", {"br_variant": 9, "br_slice": 16})):
         for o, v in opts.items():
             ctx.set_option(o, v)
