@@ -1455,3 +1455,35 @@ def test_bench_collectives_on_rccl_with_one_rank(tmp_path):
     cfg = out["config"]
     assert out["n_gpus"] == 1 and cfg["rccl_ranks"] == 1 and cfg["collective_backend"] == "nccl" and cfg["key_broadcast_s"] > 0
     assert len(cfg["per_rank_gate_ops_per_s"]) == 1 and out["value"] > 0 and out["mul32"]["mul32_per_s"] > 0
+
+
+def test_output_noise_matches_the_published_variance(ia, gpu_ctx):
+    """The algorithm pinned without a libtfhe binary: 16 384 bootstrapped gate outputs at the reference's parameters carry the
+    noise the published analysis predicts for libtfhe's conventions (tests/test_golden_cpu.py: predicted_gate_output_noise) --
+    blind rotation 4.69e-6 + truncating decomposition 1.5e-6 + key switch 4.29e-6 about a per-key offset -- to within 6 %
+    (sample variance of 16 384 values: +-1.1 % at one sigma).  A decomposition that ROUNDED would measure 15 % lower, a missing
+    digit row 8 % lower, key-switch base 8 instead of 4 36 % lower: the bits the kernels produce are those of THIS algorithm.
+    Both kernel families, two gate types (the output noise must not depend on the gate or on the inputs)."""
+    from test_golden_cpu import predicted_gate_output_noise, phase_errors
+    z = np.load(os.path.join(G, "full_gate_kat.npz"))
+    kb, ctx = gpu_ctx(630, 1024, seed=tuple(int(v) for v in z["seed"]))
+    var, offset_sd = predicted_gate_output_noise(kb.p, np.sum(kb.tlwe_key))
+    rng = np.random.default_rng(99)
+    cnt = 16384
+    bits = rng.integers(0, 2, size=(2, cnt)).astype(np.uint8)
+    a, b = kb.enc(bits[0], 171), kb.enc(bits[1], 172)
+    means = []
+    for exact, gate, want_bits in ((0, ia.GATE_XOR, bits[0] ^ bits[1]), (1, ia.GATE_NAND, 1 - (bits[0] & bits[1]))):
+        ctx.set_option("exact_fft", exact)
+        out = ctx.gates(gate, a, b)
+        ctx.set_option("exact_fft", 0)
+        assert np.array_equal(kb.dec(out), want_bits)
+        e = phase_errors(kb.p, kb.lwe_key, out, want_bits)
+        assert np.max(np.abs(e)) < 1.0 / 32                       # 1/8 is a wrong bit; 4.5 sigma of 16 384 draws is 0.016
+        assert 0.94 * var < np.var(e) < 1.06 * var, (exact, np.var(e), var)
+        means.append(float(np.mean(e)))
+        assert abs(means[-1]) < 4 * offset_sd, means
+        # the offset is the same for outputs of either sign (it is additive key-switch-key noise, not a scaling of the message)
+        m1, m0 = np.mean(e[want_bits == 1]), np.mean(e[want_bits == 0])
+        assert abs(m1 - m0) < 6 * np.sqrt(2 * var / (cnt / 2)), (m1, m0)
+    assert abs(means[0] - means[1]) < 6 * np.sqrt(2 * var / cnt), means  # one key, one offset
