@@ -1462,7 +1462,7 @@ def test_output_noise_matches_the_published_variance(ia, gpu_ctx):
     noise the published analysis predicts for libtfhe's conventions (tests/test_golden_cpu.py: predicted_gate_output_noise) --
     blind rotation 4.69e-6 + truncating decomposition 1.5e-6 + key switch 4.29e-6 about a per-key offset -- to within 6 %
     (sample variance of 16 384 values: +-1.1 % at one sigma).  A decomposition that ROUNDED would measure 15 % lower, a missing
-    digit row 8 % lower, key-switch base 8 instead of 4 36 % lower: the bits the kernels produce are those of THIS algorithm.
+    digit row 8 % lower, a key-switch base of 8 instead of 4 15 % higher: the bits the kernels produce are those of THIS algorithm.
     Both kernel families, two gate types (the output noise must not depend on the gate or on the inputs)."""
     from test_golden_cpu import predicted_gate_output_noise, phase_errors
     z = np.load(os.path.join(G, "full_gate_kat.npz"))
