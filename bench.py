@@ -276,6 +276,12 @@ def compact_roofline(r):
     vi = r.get("valu_issue") or {}
     if vi:
         out["valu_issue_utilisation"] = _r(vi.get("utilisation"))
+    if r.get("mode"):
+        out["mode"] = r["mode"].split(":")[0]
+        out["one_stream_gate_ops_per_s"] = _r(r.get("one_stream_gate_ops_per_s"))
+    tr = r.get("timed_region")
+    if tr:
+        out["timed_region"] = _pick(tr, ("streams", "frac_end_to_end", "frac_blind_rotation_in_flight"))
     return out
 
 
@@ -493,6 +499,8 @@ def main():
                     help="a leg is skipped (and named in `skipped_legs`) when the run has already taken this many seconds minus the leg's estimate")
     ap.add_argument("--metric-passes", type=int, default=2,
                     help="timed passes of the mul32 leg (the config BASELINE.json quotes its metric on); the line reports each and their spread")
+    ap.add_argument("--roofline-steps", type=int, default=3,
+                    help="steps of the primary batch run with every launch on one stream (overlap = 0) after the timed region, for the per-kernel roofline figures")
     ap.add_argument("--exact-leg", default="on", choices=["on", "off"],
                     help="after the primary leg: the same batch once more on the provably exact two-limb kernels (`exact` in the line)")
     ap.add_argument("--extras", action="store_true",
@@ -552,6 +560,20 @@ def main():
     primary_rate = info.bootstraps * batch * args.steps * world / elapsed
     progress(rank, "%s x%d: %.0f gate ops/s" % (args.workload, batch, primary_rate))
 
+    # ---- per-kernel figures: the evaluator issues wide levels as two halves on two streams (option "overlap"), whose kernels share
+    # the chip, so a launch's own duration is taken with every launch on ONE stream: a few more steps of the same batch with
+    # overlap = 0, HIP events around each launch, and the committed rocprofv3 / PMC summaries are collected in that mode too ----
+    overlap_on = bool(ctx.get_option("overlap")) and (ctx.get_option("pipelined_evals") > 0 or ctx.get_option("overlapped_levels") > 0)
+    kstats, k_rate = stats, primary_rate / world
+    if overlap_on and args.roofline_steps > 0:
+        ctx.set_option("overlap", 0)
+        step()                                            # untimed: one-stream scratch (a whole level per launch) in place
+        kstats = ia.Stats()
+        k_elapsed, _ = timed(torch, dist, world, dev, args.backend, lambda: [step(kstats) for _ in range(args.roofline_steps)])
+        ctx.set_option("overlap", 1)
+        k_rate = info.bootstraps * batch * args.roofline_steps / k_elapsed
+        progress(rank, "%s x%d on one stream (per-kernel timings): %.0f gate ops/s" % (args.workload, batch, k_rate * world))
+
     # ---- the same batch once more on the PROVABLY EXACT product (two-limb transform, exact_fft = 1): one untimed pass, one timed
     # pass, and its outputs compared word for word with the guarded one-limb pass above ----
     exact_out, skipped = None, []
@@ -589,8 +611,9 @@ def main():
                      "bit_identical_to_primary_leg": same,
                      "checked": "all %d x %d output samples equal the one-limb pass's, word for word (torch.equal on the device buffers)" % (batch, info.n_outputs),
                      "vs_primary": e_rate / primary_rate,
+                     "streams": 2 if overlap_on else 1,
                      "roofline": roofline(p, est, e_rate / world, pmc_counters(exact_kernel_variant),
-                                          ctx_kernel_exact(ctx, round(est.bootstraps / max(1, est.chunks))), limbs=2)}
+                                          ctx_kernel_exact(ctx, round((2 if overlap_on else 1) * est.bootstraps / max(1, est.chunks))), limbs=2)}
         del primary_out
     del d_in, d_out
 
@@ -603,6 +626,7 @@ def main():
         legs = [l for l in args.legs.split(",") if l and l != "none"]
     leg_batch = {"mul32": args.mul32_batch, "muladd64": args.muladd64_batch, "mul128": args.mul128_batch}
     leg_out = {}
+    streams = 2 if overlap_on else 1
     for key, wl, _, full_batch in DEFAULT_LEGS:
         if key not in legs:
             continue
@@ -644,7 +668,10 @@ def main():
                "warmup": "no warm-up pass (one is %.0f s); an untimed prepare call built the circuit and allocated the wire store and the "
                          "widest level's scratch beforehand, so the timed pass makes no allocation; every kernel it launches has run in "
                          "the primary leg" % l_elapsed,
-               "roofline": roofline(p, lst, l_rate / world, pmc, ctx.kernel_for_launch(round(lst.bootstraps / max(1, lst.chunks))))}
+               # two streams: a launch shares the chip with the other stream's launch of the same level; the evaluator picks kernels
+               # by the gate instances in flight on both, and blind_rotate_ms is the time with a rotation in flight on either
+               "streams": streams,
+               "roofline": roofline(p, lst, l_rate / world, pmc, ctx.kernel_for_launch(round(streams * lst.bootstraps / max(1, lst.chunks))))}
         if lb != full_batch:
             rec["sub_batch_of"] = full_batch
             rec["full_share_estimate_s"] = l_elapsed * full_batch / lb
@@ -684,9 +711,20 @@ def main():
                        "rccl_ranks": world if (dist is not None and args.backend == "nccl") else 0,
                        "collective_backend": args.backend if dist is not None else None,
                        "per_rank_gate_ops_per_s": [info.bootstraps * batch * args.steps / t for t in per_rank]},
-            "roofline": roofline(p, stats, value / world, pmc, ctx.kernel_for_launch(round(stats.bootstraps / max(1, stats.chunks)))),
+            "roofline": roofline(p, kstats, k_rate, pmc, ctx.kernel_for_launch(round(kstats.bootstraps / max(1, kstats.chunks)))),
             "fft_guard": fft_guard_record(ctx),
         }
+        # what the roofline object was measured on, and the timed region priced the same way (launches of both streams merged on
+        # the device timeline: EvalStats::blind_rotate_ms is the time with a blind rotation in flight)
+        alg = algorithmic_flops_per_gate(p)
+        out["roofline"]["mode"] = ("one stream (overlap = 0): %d steps of the same batch after the timed region" % args.roofline_steps) if kstats is not stats else "timed region"
+        out["roofline"]["one_stream_gate_ops_per_s"] = k_rate * world
+        out["roofline"]["timed_region"] = {
+            "streams": 2 if overlap_on else 1,
+            "frac_end_to_end": value / world * alg * 1e-12 / FP64_VALU_PEAK_TFLOPS,
+            "frac_blind_rotation_in_flight": stats.bootstraps / max(1e-9, stats.blind_rotate_ms * 1e-3) * alg * 1e-12 / FP64_VALU_PEAK_TFLOPS,
+            "blind_rotate_ms_per_step": stats.blind_rotate_ms / args.steps, "launches_per_step": stats.blind_rotate_launches / args.steps}
+        out["config"]["overlap_streams"] = 2 if overlap_on else 1
         out.update(leg_out)
         if exact_out:
             out["exact"] = exact_out

@@ -28,11 +28,14 @@ size_t state_bytes_per_item(const Params& p);
 // two-limb variants).
 int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard,
            const dev::WorkDesc& W, int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice,
-           int32_t variant, const double2* d_twiddles, hipStream_t stream);
+           int32_t variant, const double2* d_twiddles, hipStream_t stream, int wg_gates = 0);
+// wg_gates: gate instances per workgroup of the two one-wave-per-gate kernels (k_blind_rotate_w1b, guard on one coefficient
+// in four, and k_blind_rotate_x1): 1 .. 4, 0 = 4.  Four gates share a workgroup only for the twiddle table; fewer per
+// workgroup let a launch that does not fill the chip spread evenly over the CUs (LDS: 4 -> 2 workgroups per CU, 3 -> 2, 2 -> 3, 1 -> 6).
 // one-limb form (k_blind_rotate_w1): raw BK -> spectrum [n][2l][2][8][64] double2
 size_t spectrum1_elems(const Params& p);
 void prepare_spectrum1(const Params& p, const Torus32* d_bk_raw, double2* d_bkf1, hipStream_t stream);
-size_t lds_bytes_w1();
+size_t lds_bytes_w1(int wg_gates = 4);
 int gates_per_workgroup_w1();
 // the kernels' twiddle table (twiddle_table_elems() double2 in device memory), built once per context
 size_t twiddle_table_elems();

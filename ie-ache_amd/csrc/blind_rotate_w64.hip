@@ -303,22 +303,22 @@ constexpr float kGuardLimit = 0.0625f;
 // Measured and dropped (profiles/r3_w1_ab.txt; source in git history, see attic/README.md): software-pipelined rows, both
 // forward transposes cross-lane, twiddles through the buffer path, an L2 prefetch of the next step's BK blocks.
 // dynamic LDS: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2          (78 848 B -> 2 per CU)
-template <int L, int BGBIT, int GUARD, bool DIAG = false>
-__global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K, const double2* __restrict__ bkf1,
+template <int L, int BGBIT, int GUARD, bool DIAG = false, int G = kW1Gates>
+__global__ __launch_bounds__(64 * G, 2) void k_blind_rotate_w1b(DevKeys K, const double2* __restrict__ bkf1,
                                                                        const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                        int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
                                                                        Torus32* ext, unsigned* guard,
                                                                        const double2* __restrict__ gtw, unsigned long long* diag = nullptr) {
     extern __shared__ __align__(16) unsigned char smem[];
     int32_t* acc_all = reinterpret_cast<int32_t*>(smem);
-    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)kW1Gates * 2 * kN * 4);
-    double2* sTw = sT_all + kW1Gates * kTile;
+    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)G * 2 * kN * 4);
+    double2* sTw = sT_all + G * kTile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double2* sT = sT_all + wave * kTile;
     int32_t* acc = acc_all + wave * 2 * kN;
-    const int64_t item = (int64_t)blockIdx.x * kW1Gates + wave;
-    load_twiddles(sTw, gtw, tid, 64 * kW1Gates);
+    const int64_t item = (int64_t)blockIdx.x * G + wave;
+    load_twiddles(sTw, gtw, tid, 64 * G);
     __syncthreads();  // the only workgroup barrier
     if (item >= items) return;
     const LaneRoots R = make_roots(sTw, lane);
@@ -472,21 +472,21 @@ __global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_w1b(DevKeys K
 // set is consumed), block q + 2 when block q has been multiplied; the second decomposition's addresses and sign masks are
 // recomputed rather than kept from the first (46 registers).  No guard: nothing here can round wrongly.
 // dynamic LDS as k_blind_rotate_w1b: acc [4][2][1024] int32 | sT [4][kTile] double2 | tw [kTwElems] double2   (78 848 B -> 2 per CU)
-template <int L, int BGBIT>
-__global__ __launch_bounds__(64 * kW1Gates, 2) void k_blind_rotate_x1(DevKeys K, const double2* __restrict__ bkf,
+template <int L, int BGBIT, int G = kW1Gates>
+__global__ __launch_bounds__(64 * G, 2) void k_blind_rotate_x1(DevKeys K, const double2* __restrict__ bkf,
                                                                       const uint16_t* __restrict__ st_bara, int32_t nb,
                                                                       int32_t* st_acc, int64_t items, int32_t i0, int32_t i1,
                                                                       Torus32* ext, const double2* __restrict__ gtw) {
     extern __shared__ __align__(16) unsigned char smem[];
     int32_t* acc_all = reinterpret_cast<int32_t*>(smem);
-    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)kW1Gates * 2 * kN * 4);
-    double2* sTw = sT_all + kW1Gates * kTile;
+    double2* sT_all = reinterpret_cast<double2*>(smem + (size_t)G * 2 * kN * 4);
+    double2* sTw = sT_all + G * kTile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double2* sT = sT_all + wave * kTile;
     int32_t* acc = acc_all + wave * 2 * kN;
-    const int64_t item = (int64_t)blockIdx.x * kW1Gates + wave;
-    load_twiddles(sTw, gtw, tid, 64 * kW1Gates);
+    const int64_t item = (int64_t)blockIdx.x * G + wave;
+    load_twiddles(sTw, gtw, tid, 64 * G);
     __syncthreads();  // the only workgroup barrier
     if (item >= items) return;
     const LaneRoots R = make_roots(sTw, lane);
@@ -1287,7 +1287,7 @@ bool one_limb_supported(const Params& p) { return supported(p) && p.l == 3 && p.
 
 size_t spectrum_elems(const Params& p) { return (size_t)p.n * p.kpl() * 4 * kM; }
 size_t spectrum1_elems(const Params& p) { return (size_t)p.n * p.kpl() * 2 * kM; }
-size_t lds_bytes_w1() { return (size_t)(kW1Gates * kTile + kTwElems) * sizeof(double2) + (size_t)kW1Gates * 2 * kN * 4; }
+size_t lds_bytes_w1(int wg_gates) { return (size_t)(wg_gates * kTile + kTwElems) * sizeof(double2) + (size_t)wg_gates * 2 * kN * 4; }
 int gates_per_workgroup_w1() { return kW1Gates; }
 
 size_t lds_bytes(const Params& p) {
@@ -1388,9 +1388,30 @@ static int32_t w4r_flip_period() {
 template <int L, int BGBIT>
 static void launch_slice(int variant, int64_t items, hipStream_t stream, const DevKeys& K, const double2* bkf2, const double2* bkf1,
                          const uint16_t* st_bara, int32_t nb, int32_t* st_acc, int32_t i0, int32_t i1, Torus32* e, unsigned* guard,
-                         const double2* gtw) {
+                         const double2* gtw, int wg) {
     const dim3 per_gate((unsigned)items), per4((unsigned)((items + kW1Gates - 1) / kW1Gates));
-    const size_t lds_w1 = lds_bytes_w1();
+    const size_t lds_w1 = lds_bytes_w1(kW1Gates);
+    // the two kernels wide launches take, built for G = 1 .. 4 gates per workgroup (wg; evaluator: by how the launch fills the CUs)
+#define IEACHE_W1_G(GG)                                                                                                                     \
+    {                                                                                                                                       \
+        const dim3 grid((unsigned)((items + GG - 1) / GG));                                                                                 \
+        if (variant == kVariantExactOneWave) {                                                                                              \
+            IEACHE_ALLOW_LDS((k_blind_rotate_x1<L, BGBIT, GG>), lds_bytes_w1(GG))                                                           \
+            hipLaunchKernelGGL((k_blind_rotate_x1<L, BGBIT, GG>), grid, dim3(64 * GG), lds_bytes_w1(GG), stream, K, bkf2, st_bara, nb,      \
+                               st_acc, items, i0, i1, e, gtw);                                                                              \
+        } else {                                                                                                                            \
+            IEACHE_ALLOW_LDS((k_blind_rotate_w1b<L, BGBIT, 2, false, GG>), lds_bytes_w1(GG))                                                \
+            hipLaunchKernelGGL((k_blind_rotate_w1b<L, BGBIT, 2, false, GG>), grid, dim3(64 * GG), lds_bytes_w1(GG), stream, K, bkf1,        \
+                               st_bara, nb, st_acc, items, i0, i1, e, guard, gtw, (unsigned long long*)nullptr);                            \
+        }                                                                                                                                   \
+        return;                                                                                                                             \
+    }
+    if ((variant == kVariantExactOneWave || variant == kVariantOneLimbDefault) && wg >= 1 && wg < kW1Gates) {
+        if (wg == 1) IEACHE_W1_G(1)
+        if (wg == 2) IEACHE_W1_G(2)
+        IEACHE_W1_G(3)
+    }
+#undef IEACHE_W1_G
     const size_t lds_w2 = (size_t)(2 * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
     const size_t lds_w4 = (size_t)(4 * kTile + 2 * 8 * 64 + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4;
     const size_t lds_wide = (size_t)(2 * L * kTile + kTwElems) * sizeof(double2) + (size_t)2 * kN * 4 + (size_t)nb * 2;
@@ -1475,7 +1496,7 @@ int32_t default_slice() {
 
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
-           const double2* d_twiddles, hipStream_t stream) {
+           const double2* d_twiddles, hipStream_t stream, int wg_gates) {
     if (!variant_known(variant)) throw std::invalid_argument("unknown blind-rotation variant");
     if (variant_one_limb(variant) && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
@@ -1489,9 +1510,9 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
     const int32_t S = (slice >= 1 && slice <= max_slice) ? slice : default_slice();
     auto one = [&](int v, int32_t i0, int32_t i1, Torus32* e) {
         if (p.l == 3)
-            launch_slice<3, 7>(v, items, stream, K, d_bkf, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles);
+            launch_slice<3, 7>(v, items, stream, K, d_bkf, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles, wg_gates);
         else
-            launch_slice<2, 10>(v, items, stream, K, d_bkf, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles);
+            launch_slice<2, 10>(v, items, stream, K, d_bkf, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles, wg_gates);
     };
     for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;

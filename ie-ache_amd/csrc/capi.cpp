@@ -285,6 +285,20 @@ int ieache_ctx_fft_guard(const ieache_ctx* ctx, double* max_deviation, int64_t* 
     return 0;
 }
 
+int ieache_ctx_get_option(const ieache_ctx* ctx, const char* name, int64_t* value) {
+    if (!ctx || !name) return fail(IEACHE_EINVAL, "null argument");
+    if (std::string(name) == "level_quantum") {
+        if (value) *value = ctx->level_quantum ? 1 : 0;
+        return 0;
+    }
+    if (std::string(name) == "fold_constants") {
+        if (value) *value = ctx->fold ? 1 : 0;
+        return 0;
+    }
+    if (!ctx->eval->get_option(name, value)) return fail(IEACHE_EINVAL, std::string("unknown option: ") + name);
+    return 0;
+}
+
 int ieache_ctx_fft_audit(const ieache_ctx* ctx, int64_t* audits, int64_t* gates_compared, int64_t* mismatches) {
     if (!ctx) return fail(IEACHE_EINVAL, "null context");
     ctx->eval->fft_audit_counts(audits, gates_compared, mismatches);
@@ -448,6 +462,19 @@ struct DevRows {
         HIP_CHECK(hipMemcpy2D(h, width * 4, p, stride * 4, width * 4, rows, hipMemcpyDeviceToHost));
     }
 };
+// the same on the evaluator's kept staging rows (Evaluator::staging): what the gate / MUX host entry points use, so that
+// a warm call allocates nothing
+struct StagedRows {
+    Torus32* p;
+    size_t rows, stride;
+    StagedRows(Evaluator& ev, int slot, size_t r, size_t s) : p(ev.staging(slot, r * s * 4)), rows(r), stride(s) {}
+    void upload(const int32_t* h, size_t width) {
+        if (rows) HIP_CHECK(hipMemcpy2D(p, stride * 4, h, width * 4, width * 4, rows, hipMemcpyHostToDevice));
+    }
+    void download(int32_t* h, size_t width) {
+        if (rows) HIP_CHECK(hipMemcpy2D(h, width * 4, p, stride * 4, width * 4, rows, hipMemcpyDeviceToHost));
+    }
+};
 }  // namespace
 
 int ieache_gates(ieache_ctx* ctx, int gate_type, size_t count, const int32_t* a, const int32_t* b, int32_t* out,
@@ -457,7 +484,7 @@ int ieache_gates(ieache_ctx* ctx, int gate_type, size_t count, const int32_t* a,
         if (gate_type < 0 || gate_type > 3) return fail(IEACHE_EINVAL, "unknown gate type");
         const Params& p = ctx->eval->params();
         HIP_CHECK(hipSetDevice(ctx->eval->device()));
-        DevRows da(count, p.lwe_stride()), db(count, p.lwe_stride()), dout(count, p.lwe_stride());
+        StagedRows da(*ctx->eval, 0, count, p.lwe_stride()), db(*ctx->eval, 1, count, p.lwe_stride()), dout(*ctx->eval, 3, count, p.lwe_stride());
         da.upload(a, p.n + 1);
         db.upload(b, p.n + 1);
         EvalStats st;
@@ -491,7 +518,8 @@ int ieache_mux(ieache_ctx* ctx, size_t count, const int32_t* a, const int32_t* b
         if (!ctx || !a || !b || !c || !out) return fail(IEACHE_EINVAL, "null argument");
         const Params& p = ctx->eval->params();
         HIP_CHECK(hipSetDevice(ctx->eval->device()));
-        DevRows da(count, p.lwe_stride()), db(count, p.lwe_stride()), dc(count, p.lwe_stride()), dout(count, p.lwe_stride());
+        StagedRows da(*ctx->eval, 0, count, p.lwe_stride()), db(*ctx->eval, 1, count, p.lwe_stride()), dc(*ctx->eval, 2, count, p.lwe_stride()),
+            dout(*ctx->eval, 3, count, p.lwe_stride());
         da.upload(a, p.n + 1);
         db.upload(b, p.n + 1);
         dc.upload(c, p.n + 1);
@@ -750,14 +778,27 @@ int ieache_verif(const char* secret_key_path, const char* nbit_key_path, const c
 // ---- 5. resident-key daemon ----
 int64_t ieache_serve(const char* socket_path, const char* cloud_key_path, const char* nbit_key_path, int device,
                      int64_t max_requests) {
+    return ieache_serve_devices(socket_path, cloud_key_path, nbit_key_path, &device, 1, max_requests);
+}
+
+int ieache_shard_slice(size_t total, size_t parts, size_t part, size_t* first, size_t* count) {
+    if (!first || !count || parts == 0 || part >= parts) return fail(IEACHE_EINVAL, "bad shard arguments");
+    daemon_shard(total, parts, part, first, count);
+    return 0;
+}
+
+int64_t ieache_serve_devices(const char* socket_path, const char* cloud_key_path, const char* nbit_key_path, const int* devices,
+                             int n_devices, int64_t max_requests) {
     int64_t served = 0;
     const int rc = guarded([&] {
-        if (!socket_path || !cloud_key_path) return fail(IEACHE_EINVAL, "null argument");
+        if (!socket_path || !cloud_key_path || !devices) return fail(IEACHE_EINVAL, "null argument");
+        if (n_devices < 1 || n_devices > 64) return fail(IEACHE_EINVAL, "1 .. 64 devices");
         DaemonConfig cfg;
         cfg.socket_path = socket_path;
         cfg.cloud_key_path = cloud_key_path;
         if (nbit_key_path) cfg.nbit_key_path = nbit_key_path;
-        cfg.device = device;
+        cfg.device = devices[0];
+        cfg.devices.assign(devices, devices + n_devices);
         cfg.max_requests = max_requests;
         if (const char* w = getenv("IEACHE_DAEMON_BATCH_WINDOW_MS")) cfg.batch_window_ms = atoi(w) > 0 ? atoi(w) : 0;
         if (const char* m = getenv("IEACHE_DAEMON_MAX_BATCH")) cfg.max_batch = atoi(m) > 0 ? atoi(m) : 1;

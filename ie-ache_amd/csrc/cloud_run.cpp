@@ -367,25 +367,14 @@ void eval_circuit_host(Evaluator& eval, const Circuit& c, size_t batch, const To
     const Params& p = eval.params();
     const size_t S = (size_t)p.n + 1, stride = (size_t)p.lwe_stride();
     const size_t n_in = (size_t)c.n_inputs * batch, n_out = c.outputs.size() * batch;
+    if (batch == 0) return;
     HIP_CHECK(hipSetDevice(eval.device()));
-    Torus32 *d_in = nullptr, *d_out = nullptr;
-    HIP_CHECK(hipMalloc(&d_in, n_in * stride * 4));
-    if (hipMalloc(&d_out, n_out * stride * 4) != hipSuccess) {
-        (void)hipFree(d_in);
-        throw std::runtime_error("hipMalloc failed for circuit outputs");
-    }
-    try {
-        HIP_CHECK(hipMemset(d_in, 0, n_in * stride * 4));
-        HIP_CHECK(hipMemcpy2D(d_in, stride * 4, in, S * 4, S * 4, n_in, hipMemcpyHostToDevice));
-        eval.eval_circuit_device(c, batch, d_in, d_out, stats);
-        HIP_CHECK(hipMemcpy2D(out, S * 4, d_out, stride * 4, S * 4, n_out, hipMemcpyDeviceToHost));
-    } catch (...) {
-        (void)hipFree(d_in);
-        (void)hipFree(d_out);
-        throw;
-    }
-    HIP_CHECK(hipFree(d_in));
-    HIP_CHECK(hipFree(d_out));
+    // the evaluator's own staging rows: a warm call (same or smaller batch) allocates nothing
+    Torus32* d_in = eval.staging(0, n_in * stride * 4);
+    Torus32* d_out = eval.staging(3, n_out * stride * 4);
+    HIP_CHECK(hipMemcpy2D(d_in, stride * 4, in, S * 4, S * 4, n_in, hipMemcpyHostToDevice));
+    eval.eval_circuit_device(c, batch, d_in, d_out, stats);
+    HIP_CHECK(hipMemcpy2D(out, S * 4, d_out, stride * 4, S * 4, n_out, hipMemcpyDeviceToHost));
 }
 
 }  // namespace ieache

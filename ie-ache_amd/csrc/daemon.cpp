@@ -17,6 +17,7 @@
 #include <memory>
 #include <new>
 #include <stdexcept>
+#include <thread>
 #include <tuple>
 
 #include "../../include/ieache.h"
@@ -224,7 +225,7 @@ public:
         evaluate(runs);
     }
 
-    int64_t batches = 0, batched_requests = 0, largest_batch = 0;
+    int64_t batches = 0, batched_requests = 0, largest_batch = 0, sharded = 0;
 
     // returns rc; fills log and data
     int32_t handle(uint32_t op, const std::vector<unsigned char>& payload, std::string* log, std::vector<unsigned char>* data) {
@@ -233,10 +234,11 @@ public:
                 case DAEMON_PING: *log = std::string(ieache_version()) + ", key " + key_path_; return 0;
                 case DAEMON_SHUTDOWN: *log = "bye"; return 0;
                 case DAEMON_STATS: {
-                    char buf[160];
-                    snprintf(buf, sizeof buf, "evaluations=%lld batched_requests=%lld largest_batch=%lld", (long long)batches,
-                             (long long)batched_requests, (long long)largest_batch);
+                    char buf[200];
+                    snprintf(buf, sizeof buf, "evaluations=%lld batched_requests=%lld largest_batch=%lld devices=%zu sharded_evaluations=%lld device_jobs=",
+                             (long long)batches, (long long)batched_requests, (long long)largest_batch, evals_.size(), (long long)sharded);
                     *log = buf;
+                    for (size_t d = 0; d < device_jobs_.size(); d++) *log += (d ? "," : "") + std::to_string(device_jobs_[d]);
                     return 0;
                 }
                 default: *log = "unknown request"; return IEACHE_EINVAL;
@@ -261,12 +263,56 @@ private:
         const FileId id = FileId::of(path);
         if (!id.valid) throw CodecError("cannot open " + path);
         CloudKeyData ck;
-        load_cloud_key(path, &ck);
-        eval_.reset();  // frees the old key's 290 MB before the new one is uploaded
-        eval_.reset(new Evaluator(ck.p, cfg_.device));
-        eval_->load_keys_host(ck.bk.data(), ck.ksk.data());
+        load_cloud_key(path, &ck);  // read and parsed once, whatever the number of devices
+        evals_.clear();  // frees the old key's 290 MB per device before the new one is uploaded
+        eval_ = nullptr;
+        std::vector<int> devs = cfg_.devices.empty() ? std::vector<int>{cfg_.device} : cfg_.devices;
+        for (int dev : devs) {
+            evals_.emplace_back(new Evaluator(ck.p, dev));
+            evals_.back()->load_keys_host(ck.bk.data(), ck.ksk.data());
+        }
+        eval_ = evals_[0].get();
+        device_jobs_.assign(evals_.size(), 0);
         key_id_ = id;
         key_path_ = path;
+    }
+
+    // The jobs of one circuit over the daemon's devices: contiguous slices (daemon_shard), one host thread per device that
+    // has a slice, each driving its own evaluator (own stream, own key copy); nothing is exchanged between devices.  A
+    // failure on any device fails the evaluation (the first exception is rethrown once every thread has finished).
+    void eval_sharded(const std::vector<CloudJob*>& jobs, std::vector<std::vector<Torus32>>* outs) {
+        const size_t parts = std::min(evals_.size(), jobs.size());
+        if (parts <= 1) {
+            cloud_eval_jobs(*evals_[0], jobs, outs, nullptr);
+            device_jobs_[0] += (int64_t)jobs.size();
+            return;
+        }
+        outs->assign(jobs.size(), {});
+        std::vector<std::vector<std::vector<Torus32>>> part_outs(parts);
+        std::vector<std::exception_ptr> errors(parts);
+        std::vector<std::thread> threads;
+        for (size_t d = 0; d < parts; d++) {
+            threads.emplace_back([&, d] {
+                try {
+                    size_t first = 0, count = 0;
+                    daemon_shard(jobs.size(), parts, d, &first, &count);
+                    const std::vector<CloudJob*> mine(jobs.begin() + first, jobs.begin() + first + count);
+                    cloud_eval_jobs(*evals_[d], mine, &part_outs[d], nullptr);
+                } catch (...) {
+                    errors[d] = std::current_exception();
+                }
+            });
+        }
+        for (std::thread& t : threads) t.join();
+        for (const std::exception_ptr& e : errors)
+            if (e) std::rethrow_exception(e);
+        for (size_t d = 0; d < parts; d++) {
+            size_t first = 0, count = 0;
+            daemon_shard(jobs.size(), parts, d, &first, &count);
+            for (size_t i = 0; i < count; i++) (*outs)[first + i] = std::move(part_outs[d][i]);
+            device_jobs_[d] += (int64_t)count;
+        }
+        sharded++;
     }
 
     // one RUN_DIR / RUN_DATA request on its way through cloud_prepare -> (batched) evaluation -> cloud_finish
@@ -346,7 +392,7 @@ private:
             try {
                 std::vector<std::vector<Torus32>> outs;
                 const double t0 = now_s();
-                cloud_eval_jobs(*eval_, jobs, &outs, nullptr);
+                eval_sharded(jobs, &outs);
                 const double dt = now_s() - t0;
                 batches++;
                 batched_requests += (int64_t)members.size();
@@ -354,7 +400,9 @@ private:
                 for (size_t i = 0; i < members.size(); i++) {
                     Run* r = members[i];
                     try {
-                        if (members.size() > 1) fprintf(r->log.f, "cloudd: evaluated together with %zu other request(s)\n", members.size() - 1);
+                        if (members.size() > 1)
+                        fprintf(r->log.f, "cloudd: evaluated together with %zu other request(s)%s\n", members.size() - 1,
+                                evals_.size() > 1 ? (" on " + std::to_string(std::min(evals_.size(), members.size())) + " devices").c_str() : "");
                         cloud_finish(r->the_io(), r->job, outs[i].data(), outs[i].size() / ((size_t)r->job.params.n + 1), dt);
                         r->reply_ok(0);
                     } catch (...) {
@@ -370,7 +418,9 @@ private:
     }
 
     DaemonConfig cfg_;
-    std::unique_ptr<Evaluator> eval_;
+    std::vector<std::unique_ptr<Evaluator>> evals_;  // one per configured device
+    Evaluator* eval_ = nullptr;                      // evals_[0]: parameters, single-request path
+    std::vector<int64_t> device_jobs_;
     FileId key_id_;
     std::string key_path_;
     SecretKeyData nbit_;
@@ -378,6 +428,17 @@ private:
 };
 
 }  // namespace
+
+void daemon_shard(size_t total, size_t parts, size_t part, size_t* first, size_t* count) {
+    if (parts == 0 || part >= parts) {
+        *first = total;
+        *count = 0;
+        return;
+    }
+    const size_t base = total / parts, extra = total % parts;
+    *first = part * base + std::min(part, extra);
+    *count = base + (part < extra ? 1 : 0);
+}
 
 int64_t daemon_serve(const DaemonConfig& cfg) {
     sockaddr_un addr = make_addr(cfg.socket_path);

@@ -16,7 +16,8 @@
 //   op RUN_DATA : payload = i32 operator | cloud.data bytes; response data = answer.data bytes
 //                 (metadata key = the daemon's nbit key)
 //   op SHUTDOWN : no payload; the daemon answers and exits its loop
-//   op STATS    : no payload; log = "evaluations=E batched_requests=R largest_batch=B"
+//   op STATS    : no payload; log = "evaluations=E batched_requests=R largest_batch=B devices=D sharded_evaluations=S
+//                 device_jobs=j0,j1,..." (S: evaluations whose jobs were split over more than one device; j_i: jobs device i ran)
 //   rc: 0 or 126 as main() of cloud.c, negative IEACHE_E* on failure (message in log)
 #pragma once
 #include <cstddef>
@@ -39,6 +40,12 @@ struct DaemonConfig {
     std::string cloud_key_path;  // loaded before the first accept
     std::string nbit_key_path;   // for RUN_DATA; empty = nbit.key next to cloud.key
     int device = 0;
+    // Several GPUs (cloudd --devices 0,1,... / IEACHE_DEVICES): one evaluator per listed device, the cloud key read from
+    // disk once and uploaded to each; the same-circuit jobs of a round are cut into contiguous slices, one per device
+    // (daemon_shard, the rule ie-ache_amd/parallel.py's shard_slice applies across ranks), evaluated concurrently -- no
+    // exchange between devices -- and answered in request order.  A device may be listed twice (two contexts on one card:
+    // how the one-GPU test box exercises this path).  Empty = {device}.
+    std::vector<int> devices;
     int64_t max_requests = -1;   // < 0: until SHUTDOWN
     bool announce = true;        // print "cloudd: ready on <path>" once listening
     // Requests arriving within this many milliseconds of the first one of a round are answered together, those that
@@ -46,6 +53,10 @@ struct DaemonConfig {
     int batch_window_ms = 0;
     int max_batch = 256;
 };
+
+// Contiguous slice [first, first + count) of `total` jobs that part `part` of `parts` takes: sizes differ by at most one, the
+// first total % parts parts take the extra job (= parallel.shard_slice).
+void daemon_shard(size_t total, size_t parts, size_t part, size_t* first, size_t* count);
 
 // Blocks serving requests; returns the number served.  Throws on setup failure
 // (key load, GPU, bind).  A failing request is answered with a negative rc and

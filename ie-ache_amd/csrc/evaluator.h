@@ -16,8 +16,9 @@ namespace ieache {
 
 struct EvalStats {
     double total_ms = 0;         // wall time of the call on the GPU timeline (events on the stream)
-    double blind_rotate_ms = 0;  // sum over blind-rotation launches
-    double keyswitch_ms = 0;     // sum over key-switch launches
+    double blind_rotate_ms = 0;  // time with a blind-rotation launch in flight: the sum over launches on one stream; with
+                                 // overlapped levels the union of the two streams' intervals on the device timeline
+    double keyswitch_ms = 0;     // the same for key-switch launches (under overlap mostly hidden behind the other stream's rotation)
     int64_t blind_rotate_launches = 0;  // k_blind_rotate_* kernel launches (one per slice of CMux steps per chunk)
     int64_t keyswitch_launches = 0;
     int64_t chunks = 0;  // (level, chunk) work units = key-switch launches
@@ -60,13 +61,19 @@ public:
     void mux_device(size_t count, const Torus32* d_a, const Torus32* d_b, const Torus32* d_c, Torus32* d_out,
                     EvalStats* stats);
 
+    // allocates what an evaluation of `c` over `batch` expressions needs (idempotent; eval_circuit_device calls it itself)
+    void prepare_circuit(const Circuit& c, size_t batch);
     // One circuit on `batch` independent expressions.
     //   d_in  [batch][circuit.n_inputs][lwe_stride]
     //   d_out [batch][circuit.outputs.size()][lwe_stride]
-    // allocates what an evaluation of `c` over `batch` expressions needs (idempotent; eval_circuit_device calls it itself)
-    void prepare_circuit(const Circuit& c, size_t batch);
     void eval_circuit_device(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
                              EvalStats* stats);
+
+    // Device rows the host-buffer entry points stage operands (slot 0 .. 2) and results (slot 3) in: owned by the evaluator,
+    // kept between calls and grown on demand, so that a warm call allocates nothing.  Operand slots are zero outside what
+    // the caller uploads (rows of lwe_stride() words, n + 1 of them uploaded).  get_option("staging_allocations") counts
+    // the (re)allocations made so far.
+    Torus32* staging(int slot, size_t bytes);
 
     // ---- single-stage hooks (parity tests compare each against its oracle stage) ----
     // x [count][lwe_stride] -> acc [count][2][N] after `steps` CMux steps (steps<0: all n),
@@ -100,6 +107,23 @@ public:
     // fft_audit_counts), "fft_audit_inject" (test hook: 1 makes the next audit report a differing row).
     // Returns false for an unknown name or a value out of range.
     bool set_option(const std::string& name, int64_t value);
+    // "overlap" (default 1; IEACHE_OVERLAP): launches go to TWO streams of the context (own scratch each, the one key copy),
+    // so that the ragged end of one stream's launch, its key switch and its prologue run under the other stream's rotation:
+    //   * a circuit over a batch whose mean level holds at least "pipe_min" gate instances (default 8 per CU;
+    //     IEACHE_PIPE_MIN): the batch is cut into two halves of EXPRESSIONS and each half runs through every level on its own
+    //     stream -- expressions are independent, so there is one fork after the input copy and one join before the outputs
+    //     are gathered, nothing in between (add16 x 4096: +3.5 %, mul32 x 1024: +1.1 %, profiles/r5_overlap_ab.txt);
+    //     kernels are chosen by the gate instances in flight on both streams;
+    //   * otherwise (flat gate calls, narrower circuits) a level of at least "overlap_min" gate instances (default 16 per
+    //     CU; IEACHE_OVERLAP_MIN) is cut into pieces of at most half the level that alternate between the two streams, and
+    //     the next level starts when both have finished.
+    // The same gate instances go through the same kernels' arithmetic either way: output bits do not depend on it.
+    // 0 = every launch on one stream -- the mode per-kernel timings (rocprofv3 averages, bench.py's roofline) are taken
+    // in, since overlapped kernels share the chip.
+    // Current value of an option, or of a read-only figure: "cus", "resident_gates", "overlapped_levels" (levels issued as
+    // halves on two streams so far), "pipelined_evals" (circuit evaluations run as two expression-half pipelines so far),
+    // "staging_allocations".  false for an unknown name.
+    bool get_option(const std::string& name, int64_t* value) const;
     std::string kernel_variant() const;
     // name of the blind-rotation kernel a launch of `gates` gate instances takes under the current options
     std::string kernel_for_launch(int64_t gates) const;

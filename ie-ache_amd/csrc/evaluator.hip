@@ -514,8 +514,43 @@ __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus3
 }  // namespace
 
 // ------------------------------------------------------------------------
+// One stream's worth of per-launch scratch.  Lane 0 runs on the evaluator's own stream and is all a call uses unless a level
+// is overlapped (option "overlap"): then the level's gate instances are cut into pieces that alternate between lane 0 and
+// lane 1 -- a second stream of the SAME context (one copy of the key) with its own extracted-sample rows, blind-rotation
+// state, key-switch digits and audit scratch -- and lane 0 waits for lane 1 before the next level starts.
+struct Lane {
+    hipStream_t stream = nullptr;
+    Torus32* ext = nullptr;
+    size_t ext_items = 0;
+    void* br_state = nullptr;  // sliced blind rotation: accumulators + rotation amounts
+    size_t br_state_items = 0;
+    void* ks_digits = nullptr;
+    size_t ks_digits_bytes = 0;
+    Torus32* audit_ext = nullptr;
+    void* audit_state = nullptr;
+};
+
 struct Evaluator::Impl {
     Params p;
+    Lane lane[2];
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // "overlap": 1 = levels of at least overlap_min gate instances are cut in two and issued on two streams (the tail of one
+    // piece's launches fills with the other's workgroups, a piece's key switch runs under the next piece's rotation); 0 = one stream
+    int32_t overlap = 1;
+    int64_t overlap_min = 0;     // set in init(): 16 gates per CU -- each half is then a full round of resident gates
+    int64_t overlapped_levels = 0;
+    // Circuits over a batch: the batch is cut into two contiguous halves of EXPRESSIONS and each half runs through every
+    // level on its own stream -- expressions are independent, so the two pipelines never wait for each other between
+    // levels (one fork after the input copy, one join before the outputs are gathered).  Used when the circuit's mean
+    // level holds at least pipe_min gate instances over the whole batch.  While both pipelines run, a launch shares the
+    // chip with the other stream's launch of the same level: kernels are chosen by the gates in flight on BOTH streams.
+    int64_t pipe_min = 0;        // set in init(): 8 gates per CU (measured: 11 per CU +2.9 %, 4 per CU -10 %, profiles/r5_overlap_ab.txt)
+    int32_t concurrency = 1;     // streams issuing launches side by side right now (kernel choice is by cnt x concurrency)
+    int64_t pipelined_evals = 0;
+    // device rows the host-buffer entry points stage their operands and results in: kept between calls, grown on demand
+    Torus32* stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[4] = {0, 0, 0, 0};
+    int64_t stage_allocs = 0;
     DevKeys K{};
     double2* bkf = nullptr;
     double2* bkf_w64 = nullptr;  // spectrum in the wave-per-gate kernel's layout
@@ -536,21 +571,15 @@ struct Evaluator::Impl {
     int64_t audit_seq = 0;       // one-limb (level, chunk) launches so far
     int64_t audits = 0, audit_gates = 0, audit_mismatches = 0;
     bool audit_inject = false;   // test hook: the next audit reports a mismatch
-    Torus32* audit_ext = nullptr;
-    void* audit_state = nullptr;
     int cus = 0;
     bool use_w64 = false;
     bool force_generic_ks = false;
     int32_t* ksk = nullptr;
     double2* twist = nullptr;
     double2* wtab = nullptr;
-    Torus32* ext = nullptr;
     Torus32* ext_mux = nullptr;  // bootsMUX: combined extracted samples, chunk/2 rows
     size_t ext_mux_items = 0;
-    void* br_state = nullptr;  // sliced blind rotation: accumulators + rotation amounts
-    size_t br_state_items = 0;
     size_t chunk = 65536;         // gate instances per launch at most (scratch grows on demand, see grown())
-    size_t ext_items = 0;
     Torus32* store = nullptr;
     size_t store_bytes = 0;
     DevGate* d_gates = nullptr;
@@ -568,14 +597,15 @@ struct Evaluator::Impl {
     // key switch as an int8 product on the MFMA pipe (keyswitch_mfma.hip): byte-limb form of the key, digit scratch, and the
     // launch size from which it takes over from the hand-scheduled walk
     int8_t* ks_limbs = nullptr;
-    void* ks_digits = nullptr;
-    size_t ks_digits_bytes = 0;
     bool ks_mfma_ok = false;
     int64_t ks_mfma_min = 64;     // measured crossover with the per-gate walk: ~40 gates (0.08 ms either way)
     int32_t ks_mfma_split = 0;    // K split of the product; 0 = by launch size
     int32_t ks_split_max = 16;    // per-gate key switch: workgroups one gate's walk may be cut into when the launch is tiny
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
     int32_t br_variant = w64::default_variant();
+    // gate instances per workgroup of the one-wave-per-gate kernels (k_blind_rotate_w1b / _x1): 1 .. 4, 0 = by launch size
+    int32_t wg_gates = 0;
+    int64_t wg3_max = 0;          // set in init(): launches of up to this many gate instances (6 per CU) take three per workgroup
     // launches of at most this many gate instances (one per CU) use the 2L-waves-per-gate kernel in a
     // single launch: what matters there is the latency of one blind rotation, not throughput
     int64_t br_wide_max = 0;
@@ -599,11 +629,20 @@ void Evaluator::init() {
     if (device < 0 || device >= count) throw std::runtime_error("no such HIP device");
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    d_->lane[0].stream = stream_;
     {
         int cus = 0;
         HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         d_->cus = cus;
         d_->br_wide_max = cus;  // one workgroup of the wide kernel fills a CU
+        d_->overlap_min = 16 * (int64_t)cus;
+        d_->pipe_min = 8 * (int64_t)cus;
+        if (const char* e = getenv("IEACHE_PIPE_MIN")) d_->pipe_min = atoll(e);
+        d_->wg3_max = 6 * (int64_t)cus;
+        if (const char* e = getenv("IEACHE_WG_GATES")) d_->wg_gates = atoi(e) >= 0 && atoi(e) <= 4 ? atoi(e) : 0;
+        if (const char* e = getenv("IEACHE_WG3_MAX")) d_->wg3_max = atoll(e);
+        if (const char* e = getenv("IEACHE_OVERLAP")) d_->overlap = atoi(e) != 0;
+        if (const char* e = getenv("IEACHE_OVERLAP_MIN")) d_->overlap_min = atoll(e);
         // k_blind_rotate_w1: one wave per gate, 256 VGPRs -> 2 per SIMD = 8 gates per CU
         // ("exact_fft": k_blind_rotate_x1 holds 8 gates per CU too; k_blind_rotate_w2, 2 waves per gate and 35.8 KB of LDS, 4 per CU)
         resident_gates_ = 8 * cus;
@@ -682,22 +721,29 @@ Evaluator::~Evaluator() { destroy(); }
 void Evaluator::destroy() {
     if (!d_) return;
     (void)hipSetDevice(device_);
+    if (d_->lane[1].stream) (void)hipStreamSynchronize(d_->lane[1].stream);
     if (stream_) (void)hipStreamSynchronize(stream_);
     (void)hipFree(d_->bkf);
     (void)hipFree(d_->bkf_w64);
     (void)hipFree(d_->tw_w64);
     (void)hipFree(d_->bkf1_w64);
     (void)hipFree(d_->fft_guard);
-    (void)hipFree(d_->audit_ext);
-    (void)hipFree(d_->audit_state);
     (void)hipFree(d_->ksk);
     (void)hipFree(d_->ks_limbs);
-    (void)hipFree(d_->ks_digits);
     (void)hipFree(d_->twist);
     (void)hipFree(d_->wtab);
-    (void)hipFree(d_->ext);
+    for (Lane& ln : d_->lane) {
+        (void)hipFree(ln.ext);
+        (void)hipFree(ln.br_state);
+        (void)hipFree(ln.ks_digits);
+        (void)hipFree(ln.audit_ext);
+        (void)hipFree(ln.audit_state);
+    }
     (void)hipFree(d_->ext_mux);
-    (void)hipFree(d_->br_state);
+    for (Torus32* st : d_->stage) (void)hipFree(st);
+    if (d_->ev_fork) (void)hipEventDestroy(d_->ev_fork);
+    if (d_->ev_join) (void)hipEventDestroy(d_->ev_join);
+    if (d_->lane[1].stream) (void)hipStreamDestroy(d_->lane[1].stream);
     (void)hipFree(d_->store);
     (void)hipFree(d_->d_gates);
     (void)hipFree(d_->d_outs);
@@ -715,6 +761,28 @@ void Evaluator::wait_for_stream(hipStream_t producer) {
     if (e == hipSuccess) e = hipStreamWaitEvent(stream_, ev, 0);
     (void)hipEventDestroy(ev);
     HIP_CHECK(e);
+}
+
+// Staging rows for the host-buffer entry points (slot 0 .. 2: operands, 3: results).  A slot grows to at least `bytes`
+// (doubling, so a run of growing batches does not reallocate every call) and is zeroed when it is (re)allocated: callers
+// upload n + 1 words per row of lwe_stride() and rely on the padding words of OPERAND rows being zero, which holds because
+// nothing but such uploads ever writes slots 0 .. 2.  Every hipMalloc / hipFree is a device-wide synchronisation, which is
+// why a warm daemon request must not make one.
+Torus32* Evaluator::staging(int slot, size_t bytes) {
+    if (slot < 0 || slot >= 4) throw std::invalid_argument("staging slot");
+    HIP_CHECK(hipSetDevice(device_));
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (d_->stage_bytes[slot] < bytes || !d_->stage[slot]) {
+        const size_t want = std::max(bytes, std::min<size_t>(2 * d_->stage_bytes[slot], (size_t)1 << 30));
+        if (d_->stage[slot]) HIP_CHECK(hipFree(d_->stage[slot]));
+        d_->stage[slot] = nullptr;
+        d_->stage_bytes[slot] = 0;
+        HIP_CHECK(hipMalloc(&d_->stage[slot], want + 16));
+        HIP_CHECK(hipMemset(d_->stage[slot], 0, want + 16));
+        d_->stage_bytes[slot] = want;
+        d_->stage_allocs++;
+    }
+    return d_->stage[slot];
 }
 
 void Evaluator::set_chunk(size_t items) {
@@ -738,10 +806,20 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
     } else if (name == "ks_mfma_min" && value >= 0) {
         d_->ks_mfma_min = value;
     } else if (name == "ks_mfma_split" && value >= 0 && value <= 64 && (value & (value - 1)) == 0 &&
-               (value == 0 || (p_.N / 4) % value == 0)) {  // 0 = by launch size; else a power of two that divides the N/4 K-steps
+               (value == 0 || ksm::split_ok(p_, (int32_t)value))) {  // 0 = by launch size; else a power of two every split of which holds whole loop trips
         d_->ks_mfma_split = (int32_t)value;
     } else if (name == "ks_split_max" && value >= 1 && value <= 64) {
         d_->ks_split_max = (int32_t)value;
+    } else if (name == "wg_gates" && value >= 0 && value <= 4) {
+        d_->wg_gates = (int32_t)value;
+    } else if (name == "wg3_max" && value >= 0) {
+        d_->wg3_max = value;
+    } else if (name == "overlap" && (value == 0 || value == 1)) {
+        d_->overlap = (int32_t)value;
+    } else if (name == "overlap_min" && value >= 2) {
+        d_->overlap_min = value;
+    } else if (name == "pipe_min" && value >= 0) {
+        d_->pipe_min = value;
     } else if (name == "br_wide_max" && value >= 0) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 0 && value <= 4096) {  // 0 = by kernel and launch size
@@ -772,6 +850,35 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
     } else {
         return false;
     }
+    return true;
+}
+
+bool Evaluator::get_option(const std::string& name, int64_t* value) const {
+    int64_t v;
+    if (name == "overlap") v = d_->overlap;
+    else if (name == "overlap_min") v = d_->overlap_min;
+    else if (name == "overlapped_levels") v = d_->overlapped_levels;  // levels issued on two streams so far (a counter)
+    else if (name == "pipe_min") v = d_->pipe_min;
+    else if (name == "pipelined_evals") v = d_->pipelined_evals;      // circuit evaluations run as two expression-half pipelines so far
+    else if (name == "wg_gates") v = d_->wg_gates;
+    else if (name == "wg3_max") v = d_->wg3_max;
+    else if (name == "staging_allocations") v = d_->stage_allocs;  // (re)allocations of the host entry points' staging rows so far
+    else if (name == "cus") v = d_->cus;
+    else if (name == "chunk") v = (int64_t)d_->chunk;
+    else if (name == "resident_gates") v = resident_gates_;
+    else if (name == "exact_fft") v = d_->exact_fft ? 1 : 0;
+    else if (name == "exact_one_wave_min") v = d_->exact_one_wave_min;
+    else if (name == "one_limb_min") v = d_->one_limb_min;
+    else if (name == "two_wave_max") v = d_->two_wave_max;
+    else if (name == "four_wave_max") v = d_->four_wave_max;
+    else if (name == "br_wide_max") v = d_->br_wide_max;
+    else if (name == "br_variant") v = d_->br_variant;
+    else if (name == "br_slice") v = d_->br_slice;
+    else if (name == "fft_audit") v = d_->fft_audit;
+    else if (name == "ks_mfma_min") v = d_->ks_mfma_min;
+    else if (name == "ks_mfma_split") v = d_->ks_mfma_split;
+    else return false;
+    if (value) *value = v;
     return true;
 }
 
@@ -853,20 +960,38 @@ struct Timer {
     ~Timer() {
         for (auto e : ev) (void)hipEventDestroy(e);
     }
-    void mark() {
+    void mark() { mark(s); }
+    // a pair of marks brackets launches on ONE stream; pairs may come from different streams (overlapped levels)
+    void mark(hipStream_t on_stream) {
         if (!on) return;
         hipEvent_t e;
         HIP_CHECK(hipEventCreate(&e));
-        HIP_CHECK(hipEventRecord(e, s));
+        HIP_CHECK(hipEventRecord(e, on_stream));
         ev.push_back(e);
     }
+    // Time during which at least one bracketed interval was open.  On one stream the intervals follow each other and this
+    // is their sum; intervals of two streams (overlapped levels) run side by side and are merged on the common device
+    // timeline (offsets from the first event), so the figure stays "time the chip spent in these launches".
     double sum_ms() {
-        double tot = 0;
+        std::vector<std::pair<double, double>> iv;
         for (size_t i = 0; i + 1 < ev.size(); i += 2) {
-            float ms = 0;
-            HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            tot += ms;
+            float t0 = 0, dt = 0;
+            if (i) HIP_CHECK(hipEventElapsedTime(&t0, ev[0], ev[i]));
+            HIP_CHECK(hipEventElapsedTime(&dt, ev[i], ev[i + 1]));
+            iv.emplace_back((double)t0, (double)t0 + (double)dt);
         }
+        std::sort(iv.begin(), iv.end());
+        double tot = 0, lo = 0, hi = -1;
+        for (const auto& x : iv) {
+            if (hi < lo || x.first > hi) {
+                if (hi >= lo) tot += hi - lo;
+                lo = x.first;
+                hi = x.second;
+            } else if (x.second > hi) {
+                hi = x.second;
+            }
+        }
+        if (hi >= lo) tot += hi - lo;
         return tot;
     }
 };
@@ -877,6 +1002,7 @@ struct Timer {
 // per gate above; "exact_fft" / a repeat after a guard trip: the two-limb kernels).
 static void pick_br_variant(const Params& p, const Evaluator::Impl* d, int64_t cnt, int32_t* variant_out, int32_t* slice_out) {
     int32_t variant = d->br_variant, slice = d->br_slice;
+    cnt *= d->concurrency;  // the other stream's launch of the same level shares the chip: choose by the gates in flight
     if (variant == 0) {
         if (cnt <= d->br_wide_max) {
             // the latency kernel, on the one-limb spectrum unless exactness by construction is asked for
@@ -904,6 +1030,14 @@ static void pick_br_variant(const Params& p, const Evaluator::Impl* d, int64_t c
     }
     *variant_out = variant;
     *slice_out = slice;
+}
+
+// Gate instances per workgroup of the one-wave-per-gate kernels.  Four share a workgroup (for the twiddle table only) and
+// two such workgroups fill a CU; a launch of at most six gates per CU in fours leaves half the CUs with two workgroups and
+// half with one, in threes every CU gets the same six waves.
+static int pick_wg_gates(const Evaluator::Impl* d, int64_t cnt) {
+    if (d->wg_gates) return d->wg_gates;
+    return cnt * d->concurrency <= d->wg3_max ? 3 : 4;
 }
 
 std::string Evaluator::kernel_for_launch(int64_t gates) const {
@@ -934,21 +1068,22 @@ static size_t grown(size_t have, size_t need, size_t cap) {
 }
 
 // Runs `items` gate instances described by W (item0 is advanced per chunk).
-static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt,
+static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, Lane& ln, const WorkDesc& w, int64_t cnt,
                                 Torus32* ext, int32_t steps, Torus32* dbg_acc) {
+    hipStream_t stream = ln.stream;
     if (d->use_w64) {
-        if (d->br_state_items < (size_t)cnt) {
-            if (d->br_state) HIP_CHECK(hipFree(d->br_state));
-            d->br_state = nullptr;
-            const size_t items = grown(d->br_state_items, (size_t)cnt, d->chunk);
-            d->br_state_items = 0;
-            HIP_CHECK(hipMalloc(&d->br_state, items * w64::state_bytes_per_item(p)));
-            d->br_state_items = items;
+        if (ln.br_state_items < (size_t)cnt) {
+            if (ln.br_state) HIP_CHECK(hipFree(ln.br_state));
+            ln.br_state = nullptr;
+            const size_t items = grown(ln.br_state_items, (size_t)cnt, d->chunk);
+            ln.br_state_items = 0;
+            HIP_CHECK(hipMalloc(&ln.br_state, items * w64::state_bytes_per_item(p)));
+            ln.br_state_items = items;
         }
         int32_t variant, slice;
         pick_br_variant(p, d, cnt, &variant, &slice);
-        return w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, w, cnt, d->br_state, ext, steps, dbg_acc, slice, variant,
-                           d->tw_w64, stream);
+        return w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, w, cnt, ln.br_state, ext, steps, dbg_acc, slice, variant,
+                           d->tw_w64, stream, pick_wg_gates(d, cnt));
     }
     else
         hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,
@@ -963,7 +1098,8 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, hipStream_t 
 // two-limb kernels like a call whose guard tripped (Evaluator::fft_guard_tripped).  The guard watches the error LEVEL of
 // every launch; this compares BITS, of a sample.
 constexpr int64_t kAuditGates = 64;
-static void maybe_audit(const Params& p, Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt, const Torus32* ext) {
+static void maybe_audit(const Params& p, Evaluator::Impl* d, Lane& ln, const WorkDesc& w, int64_t cnt, const Torus32* ext) {
+    hipStream_t stream = ln.stream;
     if (!d->use_w64 || d->fft_audit <= 0 || !d->fft_guard) return;
     int32_t variant, slice;
     pick_br_variant(p, d, cnt, &variant, &slice);
@@ -971,13 +1107,13 @@ static void maybe_audit(const Params& p, Evaluator::Impl* d, hipStream_t stream,
     if (++d->audit_seq % d->fft_audit != 0) return;
     const int64_t m = std::min<int64_t>(kAuditGates, cnt);
     const int64_t off = cnt > m ? (int64_t)(((uint64_t)d->audit_seq * 0x9E3779B97F4A7C15ull >> 33) % (uint64_t)(cnt - m + 1)) : 0;
-    if (!d->audit_ext) HIP_CHECK(hipMalloc(&d->audit_ext, (size_t)kAuditGates * (size_t)(d->K.N + 4) * 4));
-    if (!d->audit_state) HIP_CHECK(hipMalloc(&d->audit_state, (size_t)kAuditGates * w64::state_bytes_per_item(p)));
+    if (!ln.audit_ext) HIP_CHECK(hipMalloc(&ln.audit_ext, (size_t)kAuditGates * (size_t)(d->K.N + 4) * 4));
+    if (!ln.audit_state) HIP_CHECK(hipMalloc(&ln.audit_state, (size_t)kAuditGates * w64::state_bytes_per_item(p)));
     WorkDesc wa = w;
     wa.item0 = w.item0 + off;
-    w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, wa, m, d->audit_state, d->audit_ext, -1, nullptr, w64::bara_stride(p),
+    w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, wa, m, ln.audit_state, ln.audit_ext, -1, nullptr, w64::bara_stride(p),
                 w64::kVariantWide, d->tw_w64, stream);
-    hipLaunchKernelGGL(k_audit_compare, dim3((unsigned)m), dim3(256), 0, stream, ext + (size_t)off * (size_t)(d->K.N + 4), d->audit_ext,
+    hipLaunchKernelGGL(k_audit_compare, dim3((unsigned)m), dim3(256), 0, stream, ext + (size_t)off * (size_t)(d->K.N + 4), ln.audit_ext,
                        d->K.N, d->fft_guard + 2, d->audit_inject ? 1 : 0);
     HIP_CHECK(hipGetLastError());
     d->audit_inject = false;
@@ -986,27 +1122,28 @@ static void maybe_audit(const Params& p, Evaluator::Impl* d, hipStream_t stream,
 }
 
 // digit scratch of the MFMA key switch for launches of up to `cnt` gates (doubling from 4 096 gates' worth, capped at a chunk's)
-static void reserve_ks_digits(Evaluator::Impl* d, int64_t cnt) {
+static void reserve_ks_digits(Evaluator::Impl* d, Lane& ln, int64_t cnt) {
     const size_t need = ksm::digit_scratch_bytes(d->p, cnt);
-    if (d->ks_digits_bytes >= need) return;
-    const size_t have = d->ks_digits_bytes;
-    if (d->ks_digits) HIP_CHECK(hipFree(d->ks_digits));
-    d->ks_digits = nullptr;
-    d->ks_digits_bytes = 0;
+    if (ln.ks_digits_bytes >= need) return;
+    const size_t have = ln.ks_digits_bytes;
+    if (ln.ks_digits) HIP_CHECK(hipFree(ln.ks_digits));
+    ln.ks_digits = nullptr;
+    ln.ks_digits_bytes = 0;
     const size_t want = std::max(need, std::min(ksm::digit_scratch_bytes(d->p, (int64_t)d->chunk),
                                                 std::max<size_t>(2 * have, ksm::digit_scratch_bytes(d->p, 4096))));
-    HIP_CHECK(hipMalloc(&d->ks_digits, want));
-    d->ks_digits_bytes = want;
+    HIP_CHECK(hipMalloc(&ln.ks_digits, want));
+    ln.ks_digits_bytes = want;
 }
 
-static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkDesc& w, int64_t cnt, const Torus32* ext,
+static void launch_keyswitch(Evaluator::Impl* d, Lane& ln, const WorkDesc& w, int64_t cnt, const Torus32* ext,
                              Torus32* flat_out, bool force_generic) {
+    hipStream_t stream = ln.stream;
     const DevKeys& K = d->K;
     const dim3 grid((unsigned)cnt), blk(kKsThreads);
     const int nld = force_generic ? 0 : d->ks_nld;
     if (!force_generic && d->ks_mfma_ok && d->ks_limbs && cnt >= d->ks_mfma_min) {
-        reserve_ks_digits(d, cnt);
-        ksm::launch(d->p, K, w, cnt, ext, flat_out, d->ks_limbs, d->ks_digits, d->ks_mfma_split, d->cus, stream);
+        reserve_ks_digits(d, ln, cnt);
+        ksm::launch(d->p, K, w, cnt, ext, flat_out, d->ks_limbs, ln.ks_digits, d->ks_mfma_split, d->cus, stream);
         return;
     }
     if (nld > 0 && d->ks_sliced_ok && cnt >= d->ks_sliced_min) {
@@ -1038,61 +1175,112 @@ static void launch_keyswitch(Evaluator::Impl* d, hipStream_t stream, const WorkD
     }
 }
 
-// Before an evaluation starts: scratch for its widest launch in one go (the per-launch checks below then find it in place),
-// so that a circuit whose levels widen does not reallocate -- and synchronise -- between them.
-static void reserve_scratch(const Params& p, Evaluator::Impl* d, int64_t widest_items) {
-    const size_t need = std::min<size_t>(d->chunk, (size_t)std::max<int64_t>(widest_items, 1));
-    if (d->ext_items < need) {
-        const size_t n = grown(d->ext_items, need, d->chunk);
-        if (d->ext) HIP_CHECK(hipFree(d->ext));
-        d->ext = nullptr;
-        d->ext_items = 0;
-        HIP_CHECK(hipMalloc(&d->ext, n * (size_t)(d->K.N + 4) * 4));
-        d->ext_items = n;
+// How a level of `items` gate instances is issued: on lane 0 in pieces of at most a chunk, or (overlap) in pieces of at most
+// half the level that alternate between the two lanes.
+struct LevelPlan {
+    bool two_lanes;
+    int64_t piece;  // gate instances per (blind rotation, key switch) pair of launches at most
+};
+static LevelPlan plan_level(const Evaluator::Impl* d, int64_t items) {
+    const int64_t chunk = (int64_t)d->chunk;
+    LevelPlan pl{false, chunk};
+    if (d->overlap && d->use_w64 && d->concurrency == 1 && items >= d->overlap_min && items >= 2) {
+        pl.two_lanes = true;
+        const int64_t half = (((items + 1) / 2) + 3) & ~(int64_t)3;  // whole workgroups of the one-wave-per-gate kernels
+        pl.piece = std::min(chunk, half);
     }
-    if (d->use_w64 && d->br_state_items < need) {
-        const size_t n = grown(d->br_state_items, need, d->chunk);
-        if (d->br_state) HIP_CHECK(hipFree(d->br_state));
-        d->br_state = nullptr;
-        d->br_state_items = 0;
-        HIP_CHECK(hipMalloc(&d->br_state, n * w64::state_bytes_per_item(p)));
-        d->br_state_items = n;
-    }
-    // the MFMA key switch's digit scratch for the widest launch that will take it
-    if (!d->force_generic_ks && d->ks_mfma_ok && d->ks_limbs && (int64_t)need >= d->ks_mfma_min) reserve_ks_digits(d, (int64_t)need);
+    return pl;
 }
 
-static void run_items(const Params& p, Evaluator::Impl* d, hipStream_t stream, WorkDesc W, int64_t items,
-                      Timer& tbr, Timer& tks, EvalStats* stats) {
-    const DevKeys& K = d->K;
-    const size_t chunk = d->chunk;
-    const size_t ext_need = std::min<size_t>(chunk, (size_t)std::max<int64_t>(items, 1));
-    if (d->ext_items < ext_need) {
-        const size_t n = grown(d->ext_items, ext_need, chunk);
-        if (d->ext) HIP_CHECK(hipFree(d->ext));
-        d->ext = nullptr;
-        d->ext_items = 0;
-        HIP_CHECK(hipMalloc(&d->ext, n * (size_t)(K.N + 4) * 4));
-        d->ext_items = n;
+static void reserve_lane(const Params& p, Evaluator::Impl* d, Lane& ln, size_t need) {
+    if (ln.ext_items < need) {
+        const size_t n = grown(ln.ext_items, need, d->chunk);
+        if (ln.ext) HIP_CHECK(hipFree(ln.ext));
+        ln.ext = nullptr;
+        ln.ext_items = 0;
+        HIP_CHECK(hipMalloc(&ln.ext, n * (size_t)(d->K.N + 4) * 4));
+        ln.ext_items = n;
     }
-    for (int64_t done = 0; done < items; done += (int64_t)chunk) {
-        const int64_t cnt = std::min<int64_t>((int64_t)chunk, items - done);
+    if (d->use_w64 && ln.br_state_items < need) {
+        const size_t n = grown(ln.br_state_items, need, d->chunk);
+        if (ln.br_state) HIP_CHECK(hipFree(ln.br_state));
+        ln.br_state = nullptr;
+        ln.br_state_items = 0;
+        HIP_CHECK(hipMalloc(&ln.br_state, n * w64::state_bytes_per_item(p)));
+        ln.br_state_items = n;
+    }
+    // the MFMA key switch's digit scratch for the widest launch that will take it
+    if (!d->force_generic_ks && d->ks_mfma_ok && d->ks_limbs && (int64_t)need >= d->ks_mfma_min) reserve_ks_digits(d, ln, (int64_t)need);
+}
+
+static void ensure_second_lane(Evaluator::Impl* d) {
+    if (!d->lane[1].stream) HIP_CHECK(hipStreamCreateWithFlags(&d->lane[1].stream, hipStreamNonBlocking));
+    if (!d->ev_fork) HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+    if (!d->ev_join) HIP_CHECK(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+}
+
+// Before an evaluation starts: scratch for its widest launch in one go (the per-launch checks below then find it in place),
+// so that a circuit whose levels widen does not reallocate -- and synchronise -- between them.  level_items: gate instances
+// of each level the evaluation will issue.
+static void reserve_scratch(const Params& p, Evaluator::Impl* d, const int64_t* level_items, size_t n_levels) {
+    size_t need0 = 1, need1 = 0;
+    for (size_t i = 0; i < n_levels; i++) {
+        const int64_t items = std::max<int64_t>(level_items[i], 1);
+        const LevelPlan pl = plan_level(d, items);
+        const size_t piece = (size_t)std::min<int64_t>(pl.piece, items);
+        need0 = std::max(need0, piece);
+        if (pl.two_lanes) need1 = std::max(need1, std::min<size_t>(piece, (size_t)(items - (int64_t)piece)));
+    }
+    reserve_lane(p, d, d->lane[0], need0);
+    if (need1) {
+        ensure_second_lane(d);
+        reserve_lane(p, d, d->lane[1], need1);
+    }
+}
+
+// One level: `items` independent gate instances described by W (item0 is advanced per piece).  Everything queued so far
+// on lane 0 (the previous level) is complete before any piece starts; lane 0 has every piece behind it when this returns.
+// fixed_lane >= 0: the whole level on that lane, in pieces of at most a chunk, no fork / join (a pipeline of its own, see
+// eval_circuit_device_once); its scratch has been reserved by the caller.
+static void run_items(const Params& p, Evaluator::Impl* d, WorkDesc W, int64_t items, Timer& tbr, Timer& tks, EvalStats* stats,
+                      int fixed_lane = -1) {
+    LevelPlan pl = plan_level(d, items);
+    if (fixed_lane >= 0) {
+        pl.two_lanes = false;
+        pl.piece = (int64_t)d->chunk;
+        reserve_lane(p, d, d->lane[fixed_lane], (size_t)std::min<int64_t>(pl.piece, std::max<int64_t>(items, 1)));
+    } else {
+        reserve_scratch(p, d, &items, 1);
+    }
+    if (pl.two_lanes) {
+        HIP_CHECK(hipEventRecord(d->ev_fork, d->lane[0].stream));
+        HIP_CHECK(hipStreamWaitEvent(d->lane[1].stream, d->ev_fork, 0));
+        d->overlapped_levels++;
+    }
+    int k = 0;
+    for (int64_t done = 0; done < items; done += pl.piece, k++) {
+        const int64_t cnt = std::min<int64_t>(pl.piece, items - done);
+        Lane& ln = d->lane[fixed_lane >= 0 ? fixed_lane : (pl.two_lanes ? (k & 1) : 0)];
         WorkDesc w = W;
         w.item0 = W.item0 + done;
-        tbr.mark();
-        const int nbr = launch_blind_rotate(p, d, stream, w, cnt, d->ext, -1, nullptr);
-        tbr.mark();
+        tbr.mark(ln.stream);
+        const int nbr = launch_blind_rotate(p, d, ln, w, cnt, ln.ext, -1, nullptr);
+        tbr.mark(ln.stream);
         HIP_CHECK(hipGetLastError());
-        maybe_audit(p, d, stream, w, cnt, d->ext);
-        tks.mark();
-        launch_keyswitch(d, stream, w, cnt, d->ext, nullptr, d->force_generic_ks);
-        tks.mark();
+        maybe_audit(p, d, ln, w, cnt, ln.ext);
+        tks.mark(ln.stream);
+        launch_keyswitch(d, ln, w, cnt, ln.ext, nullptr, d->force_generic_ks);
+        tks.mark(ln.stream);
         HIP_CHECK(hipGetLastError());
         if (stats) {
             stats->blind_rotate_launches += nbr;
             stats->keyswitch_launches++;
             stats->chunks++;
         }
+    }
+    if (pl.two_lanes) {
+        HIP_CHECK(hipEventRecord(d->ev_join, d->lane[1].stream));
+        HIP_CHECK(hipStreamWaitEvent(d->lane[0].stream, d->ev_join, 0));
     }
     if (stats) stats->bootstraps += items;
 }
@@ -1207,7 +1395,7 @@ void Evaluator::gates_device_once(int32_t type, size_t count, const Torus32* d_a
     W.flat_type = type;
     W.item0 = 0;
     tall.mark();
-    run_items(p_, d_, stream_, W, (int64_t)count, tbr, tks, stats);
+    run_items(p_, d_, W, (int64_t)count, tbr, tks, stats);
     tall.mark();
     HIP_CHECK(hipStreamSynchronize(stream_));
     if (stats) {
@@ -1229,13 +1417,14 @@ void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32*
     const DevKeys& K = d_->K;
     const size_t chunk = std::max<size_t>(d_->chunk & ~(size_t)1, 2), gates_per_chunk = chunk / 2;
     const size_t mux_need = std::min(gates_per_chunk, count);  // two extracted samples per MUX gate
-    if (d_->ext_items < 2 * mux_need) {
-        const size_t n = grown(d_->ext_items, 2 * mux_need, chunk);
-        if (d_->ext) HIP_CHECK(hipFree(d_->ext));
-        d_->ext = nullptr;
-        d_->ext_items = 0;
-        HIP_CHECK(hipMalloc(&d_->ext, n * (size_t)(K.N + 4) * 4));
-        d_->ext_items = n;
+    Lane& ln = d_->lane[0];
+    if (ln.ext_items < 2 * mux_need) {
+        const size_t n = grown(ln.ext_items, 2 * mux_need, chunk);
+        if (ln.ext) HIP_CHECK(hipFree(ln.ext));
+        ln.ext = nullptr;
+        ln.ext_items = 0;
+        HIP_CHECK(hipMalloc(&ln.ext, n * (size_t)(K.N + 4) * 4));
+        ln.ext_items = n;
     }
     if (d_->ext_mux_items < mux_need) {
         const size_t n = grown(d_->ext_mux_items, mux_need, gates_per_chunk);
@@ -1256,14 +1445,14 @@ void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32*
         W.flat_type = kFlatMux;
         W.item0 = 0;
         tbr.mark();
-        const int nbr = launch_blind_rotate(p_, d_, stream_, W, 2 * cnt, d_->ext, -1, nullptr);
+        const int nbr = launch_blind_rotate(p_, d_, ln, W, 2 * cnt, ln.ext, -1, nullptr);
         tbr.mark();
         HIP_CHECK(hipGetLastError());
-        maybe_audit(p_, d_, stream_, W, 2 * cnt, d_->ext);
+        maybe_audit(p_, d_, ln, W, 2 * cnt, ln.ext);
         tks.mark();
-        hipLaunchKernelGGL(k_mux_combine, dim3((unsigned)cnt), dim3(256), 0, stream_, d_->ext, d_->ext_mux, K.N);
+        hipLaunchKernelGGL(k_mux_combine, dim3((unsigned)cnt), dim3(256), 0, stream_, ln.ext, d_->ext_mux, K.N);
         WorkDesc Wk{};
-        launch_keyswitch(d_, stream_, Wk, cnt, d_->ext_mux, d_out + done * K.stride, d_->force_generic_ks);
+        launch_keyswitch(d_, ln, Wk, cnt, d_->ext_mux, d_out + done * K.stride, d_->force_generic_ks);
         tks.mark();
         HIP_CHECK(hipGetLastError());
         if (stats) {
@@ -1287,6 +1476,13 @@ void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32*
 // of its widest level (extracted samples, blind-rotation state, key-switch digits) -- so that the evaluation itself makes no
 // allocation (each one is a device-wide synchronisation).  eval_circuit_device calls it; a caller that times its first
 // evaluation calls it beforehand (ieache_prepare_batch).
+// Whether an evaluation of `c` over `batch` expressions runs as two expression-half pipelines (Impl::pipe_min).
+static bool pipelined(const Evaluator::Impl* d, const Circuit& c, size_t batch) {
+    if (!d->overlap || !d->use_w64 || batch < 2 || c.n_levels() < 1) return false;
+    const int64_t gates = (int64_t)c.level_offset[c.n_levels()] - (int64_t)c.level_offset[0];
+    return gates * (int64_t)batch >= d->pipe_min * (int64_t)c.n_levels();
+}
+
 void Evaluator::prepare_circuit(const Circuit& c, size_t batch) {
     if (!keys_loaded_) throw std::runtime_error("cloud key not loaded");
     HIP_CHECK(hipSetDevice(device_));
@@ -1316,10 +1512,20 @@ void Evaluator::prepare_circuit(const Circuit& c, size_t batch) {
         HIP_CHECK(hipMalloc(&d_->d_outs, c.outputs.size() * sizeof(OutRef)));
         d_->d_outs_cap = c.outputs.size();
     }
-    int64_t widest = 1;
+    std::vector<int64_t> level_items;
     for (int32_t L = 1; L <= c.n_levels(); L++)
-        widest = std::max<int64_t>(widest, (int64_t)(c.level_offset[L] - c.level_offset[L - 1]) * (int64_t)batch);
-    reserve_scratch(p_, d_, widest);
+        level_items.push_back((int64_t)(c.level_offset[L] - c.level_offset[L - 1]) * (int64_t)batch);
+    if (pipelined(d_, c, batch)) {
+        // two pipelines of batch / 2 expressions each (the first takes the odd one)
+        int64_t widest = 1;
+        for (int32_t L = 1; L <= c.n_levels(); L++) widest = std::max<int64_t>(widest, c.level_offset[L] - c.level_offset[L - 1]);
+        ensure_second_lane(d_);
+        const size_t b0 = (batch + 1) / 2, b1 = batch - b0;
+        reserve_lane(p_, d_, d_->lane[0], std::min<size_t>(d_->chunk, (size_t)widest * b0));
+        reserve_lane(p_, d_, d_->lane[1], std::min<size_t>(d_->chunk, (size_t)widest * b1));
+    } else {
+        reserve_scratch(p_, d_, level_items.data(), level_items.size());
+    }
 }
 
 void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const Torus32* d_in, Torus32* d_out,
@@ -1340,16 +1546,42 @@ void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const T
     // inputs -> slots 0..n_inputs-1 of every expression
     HIP_CHECK(hipMemcpy2DAsync(d_->store, (size_t)c.n_slots * row_bytes, d_in, (size_t)c.n_inputs * row_bytes,
                                (size_t)c.n_inputs * row_bytes, batch, hipMemcpyDeviceToDevice, stream_));
-    for (int32_t L = 1; L <= c.n_levels(); L++) {
-        WorkDesc W{};
-        W.gates = d_->d_gates;
-        W.g0 = c.level_offset[L - 1];
-        W.ng = c.level_offset[L] - c.level_offset[L - 1];
-        W.store = d_->store;
-        W.n_slots = c.n_slots;
-        W.item0 = 0;
-        run_items(p_, d_, stream_, W, (int64_t)W.ng * (int64_t)batch, tbr, tks, stats);
-        if (stats) stats->levels++;
+    const bool pipes = pipelined(d_, c, batch);
+    if (pipes) {
+        // fork: the second pipeline starts when the inputs are in the wire store
+        HIP_CHECK(hipEventRecord(d_->ev_fork, d_->lane[0].stream));
+        HIP_CHECK(hipStreamWaitEvent(d_->lane[1].stream, d_->ev_fork, 0));
+        d_->concurrency = 2;
+        d_->pipelined_evals++;
+    }
+    const int64_t half0 = pipes ? (int64_t)((batch + 1) / 2) : (int64_t)batch;
+    try {
+        for (int32_t L = 1; L <= c.n_levels(); L++) {
+            WorkDesc W{};
+            W.gates = d_->d_gates;
+            W.g0 = c.level_offset[L - 1];
+            W.ng = c.level_offset[L] - c.level_offset[L - 1];
+            W.store = d_->store;
+            W.n_slots = c.n_slots;
+            W.item0 = 0;
+            if (!pipes) {
+                run_items(p_, d_, W, (int64_t)W.ng * (int64_t)batch, tbr, tks, stats);
+            } else {
+                // items are expression-major (item = expression x ng + gate): [0, ng x half0) is the first half of the batch
+                run_items(p_, d_, W, (int64_t)W.ng * half0, tbr, tks, stats, 0);
+                W.item0 = (int64_t)W.ng * half0;
+                run_items(p_, d_, W, (int64_t)W.ng * ((int64_t)batch - half0), tbr, tks, stats, 1);
+            }
+            if (stats) stats->levels++;
+        }
+    } catch (...) {
+        d_->concurrency = 1;
+        throw;
+    }
+    if (pipes) {
+        d_->concurrency = 1;
+        HIP_CHECK(hipEventRecord(d_->ev_join, d_->lane[1].stream));
+        HIP_CHECK(hipStreamWaitEvent(d_->lane[0].stream, d_->ev_join, 0));
     }
     const int32_t n_out = (int32_t)c.outputs.size();
     hipLaunchKernelGGL(k_gather_outputs, dim3((unsigned)(batch * n_out)), dim3(128), 0, stream_, d_->d_outs, n_out,
@@ -1374,7 +1606,7 @@ void Evaluator::debug_blind_rotate_once(size_t count, const Torus32* d_x, Torus3
     W.flat_type = -1;
     d_->use_w64 = w64::supported(p_) && !force_generic_;
     d_->force_generic_ks = force_generic_;
-    launch_blind_rotate(p_, d_, stream_, W, (int64_t)count, nullptr, steps, d_acc);
+    launch_blind_rotate(p_, d_, d_->lane[0], W, (int64_t)count, nullptr, steps, d_acc);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
@@ -1388,7 +1620,7 @@ void Evaluator::debug_keyswitch(size_t count, const Torus32* d_u, Torus32* d_out
     HIP_CHECK(hipMemcpy2DAsync(tmp, (size_t)(p_.N + 4) * 4, d_u, (size_t)(p_.N + 1) * 4, (size_t)(p_.N + 1) * 4, count,
                                hipMemcpyDeviceToDevice, stream_));
     WorkDesc W{};
-    launch_keyswitch(d_, stream_, W, (int64_t)count, tmp, d_out, force_generic_);
+    launch_keyswitch(d_, d_->lane[0], W, (int64_t)count, tmp, d_out, force_generic_);
     hipError_t e = hipGetLastError();
     (void)hipStreamSynchronize(stream_);
     (void)hipFree(tmp);

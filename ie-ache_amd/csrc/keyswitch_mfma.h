@@ -7,6 +7,9 @@ namespace ksm {
 
 // libtfhe's key-switch decomposition t = 8, basebit = 2: one coefficient = 8 positions x 4 digit values = one K-step of 32
 bool supported(const Params& p);
+// a K split the product accepts: divides the N / 4 digit groups and leaves each split a whole number of its loop's trips
+// (two groups per trip with B fragments eight coefficients ahead): N = 1024 -> 1 .. 128, N = 64 -> 1 .. 8
+bool split_ok(const Params& p, int32_t ksplit);
 // bytes of the byte-limb form of the key-switch key (built once per key load): N * ceil(stride / 32) * 4096
 size_t limb_matrix_bytes(const Params& p);
 // bytes of digit scratch for launches of up to `items` gate instances

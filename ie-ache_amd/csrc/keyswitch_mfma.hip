@@ -157,7 +157,8 @@ __global__ __launch_bounds__(64 * kWgWaves) void k_ksm_gemm(const v4i* __restric
     // buffer c holds coefficient 4 i4 + c (kAhead = 8: of two consecutive i4) and is refilled with the coefficient kAhead further
     // on right after its products are issued
     constexpr int kAhead = IEACHE_KS_AHEAD;   // 4 or 8
-    constexpr int kGroups = kAhead / 4;       // i4 values per trip of the loop
+    constexpr int kGroups = kAhead / 4;       // i4 values per trip of the loop: every K split must hold a whole number of trips (split_ok)
+    static_assert(kAhead == 4 || kAhead == 8, "IEACHE_KS_AHEAD: B fragments are requested 4 or 8 coefficients ahead");
     v4i bq[kAhead][4];
     const v4i* bp0 = limbs + (size_t)cb * 256 + lane;
 #pragma unroll
@@ -210,6 +211,16 @@ __global__ __launch_bounds__(64 * kWgWaves) void k_ksm_gemm(const v4i* __restric
 
 }  // namespace
 
+// A K split is usable when it divides the N / 4 digit groups and leaves every split a whole number (>= 1) of the loop's trips
+// of IEACHE_KS_AHEAD / 4 groups: the B fragments are preloaded a whole trip ahead, so a split shorter than a trip would multiply
+// the NEXT split's fragments by stale digits and preload past the end of the limb table.
+bool split_ok(const Params& p, int32_t ksplit) {
+    constexpr int32_t groups_per_trip = IEACHE_KS_AHEAD / 4;
+    if (ksplit < 1 || (p.N / 4) % ksplit != 0) return false;
+    const int32_t per_split = p.N / 4 / ksplit;
+    return per_split >= groups_per_trip && per_split % groups_per_trip == 0;
+}
+
 bool supported(const Params& p) { return p.ks_t == 8 && p.ks_basebit == 2 && p.k == 1 && p.N % 64 == 0 && p.N >= 64; }
 
 static int32_t coef_blocks(const Params& p) { return (p.lwe_stride() + 31) / 32; }
@@ -243,7 +254,7 @@ int launch(const Params& p, const DevKeys& K, const WorkDesc& W, int64_t items, 
         const int64_t W0 = gblocks * ncb;
         double best = 0;
         for (int32_t k = 1; k <= 8; k *= 2) {
-            if ((p.N / 4) % k != 0) break;
+            if (!split_ok(p, k)) break;
             const double cost = (double)((W0 * k + cus - 1) / cus) / k + 0.02 * k;
             if (ksplit <= 0 || cost < best) {
                 best = cost;
@@ -251,7 +262,7 @@ int launch(const Params& p, const DevKeys& K, const WorkDesc& W, int64_t items, 
             }
         }
     }
-    if ((p.N / 4) % ksplit != 0) throw std::invalid_argument("key-switch K split does not divide N / 4");
+    if (!split_ok(p, ksplit)) throw std::invalid_argument("key-switch K split does not leave every split a whole trip of the product's loop");
     static const int32_t xcd_map = getenv("IEACHE_KS_XCD") ? atoi(getenv("IEACHE_KS_XCD")) : 0;  // measurement aid, see k_ksm_gemm
     hipLaunchKernelGGL(k_ksm_digits, dim3((unsigned)(p.N / 64), (unsigned)(gpad / 64)), dim3(256), 0, stream, ext, dig4, items, gpad, p.N);
     hipLaunchKernelGGL(k_ksm_init, dim3((unsigned)items), dim3(256), 0, stream, K, W, ext, flat_out, out_ptr);

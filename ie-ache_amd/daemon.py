@@ -84,25 +84,36 @@ def run_data(socket_path, operator_code, cloud_data):
 
 
 def stats(socket_path):
-    """-> dict(evaluations, batched_requests, largest_batch): how the daemon has grouped its RUN_* requests so far."""
+    """-> dict(evaluations, batched_requests, largest_batch, devices, sharded_evaluations, device_jobs): how the daemon has
+    grouped its RUN_* requests so far and, with several devices, how many jobs each one ran (a list)."""
     rc, log, _ = request(socket_path, OP_STATS, timeout=30.0)
     if rc != 0:
         raise DaemonError("stats: %s" % log)
-    return {k: int(v) for k, v in (kv.split("=") for kv in log.split())}
+    return parse_stats(log)
+
+
+def parse_stats(log):
+    out = {}
+    for kv in log.split():
+        k, v = kv.split("=")
+        out[k] = [int(x) for x in v.split(",") if x != ""] if k == "device_jobs" else int(v)
+    return out
 
 
 def shutdown(socket_path):
     return request(socket_path, OP_SHUTDOWN, timeout=30.0)[0]
 
 
-def spawn(socket_path, cloud_key, nbit_key=None, device=0, wait=120.0, env=None, batch_window_ms=0, max_batch=None):
+def spawn(socket_path, cloud_key, nbit_key=None, device=0, wait=120.0, env=None, batch_window_ms=0, max_batch=None, devices=None):
     """Start `cloudd` and wait until it answers a ping (the key load + transform take ~0.4 s at n=630).
     batch_window_ms > 0: requests arriving within that window are answered together, same-circuit ones as one
     level-batched GPU run (csrc/daemon.h)."""
     exe = os.path.join(_PKG, "cloudd")
     if not os.path.exists(exe):
         raise DaemonError("%s is missing: run __graft_entry__.build()" % exe)
-    cmd = [exe, "--socket", os.fspath(socket_path), "--key", os.fspath(cloud_key), "--device", str(device)]
+    cmd = [exe, "--socket", os.fspath(socket_path), "--key", os.fspath(cloud_key)]
+    # devices=[0, 1, ...]: one evaluator per listed GPU, a round's same-circuit requests sliced across them (csrc/daemon.h)
+    cmd += ["--devices", ",".join(str(int(d)) for d in devices)] if devices else ["--device", str(device)]
     if nbit_key:
         cmd += ["--nbit", os.fspath(nbit_key)]
     if batch_window_ms:

@@ -122,6 +122,7 @@ def lib():
     L.ieache_ctx_set_chunk.argtypes = [vp, C.c_int64]
     L.ieache_ctx_force_generic.argtypes = [vp, C.c_int]
     L.ieache_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.ieache_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.ieache_ctx_fft_guard.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.ieache_ctx_fft_audit.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ieache_ctx_kernel_variant.restype = C.c_char_p
@@ -160,6 +161,9 @@ def lib():
     L.ieache_verif.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, u32p, u32p, u32p]
     L.ieache_serve.restype = C.c_int64
     L.ieache_serve.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int64]
+    L.ieache_serve_devices.restype = C.c_int64
+    L.ieache_serve_devices.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int64]
+    L.ieache_shard_slice.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ieache_client_ping.argtypes = [C.c_char_p]
     L.ieache_client_run_dir.argtypes = [C.c_char_p, C.c_char_p]
     L.ieache_client_run_data.argtypes = [C.c_char_p, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -293,6 +297,16 @@ class Context:
         check(lib().ieache_ctx_set_option(self.h, name.encode(), int(value)))
         if name == "fold_constants":
             self._fold = bool(value)
+
+    def set_option_ok(self, name, value):
+        """set_option without raising: False when the name is unknown or the value out of range (nothing is changed then)."""
+        return lib().ieache_ctx_set_option(self.h, name.encode(), int(value)) == 0
+
+    def get_option(self, name):
+        """Current value of an option, or of a read-only figure ("cus", "resident_gates", "overlapped_levels")."""
+        v = C.c_int64(0)
+        check(lib().ieache_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def wait_stream(self, hip_stream=None):
         """Order the context's stream after the work queued on `hip_stream` (int handle; None = default stream)."""

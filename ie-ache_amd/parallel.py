@@ -75,3 +75,29 @@ def gather_to_rank0(dist, local):
     if dist.get_rank() != 0:
         return None
     return np.concatenate(objs, axis=0)
+
+
+def eval_batch_sharded(ctx, kind, bits, in_lwe, dist, src=0, stats=None):
+    """One circuit over a batch of expressions spread over the ranks of a torchrun job (one rank per GPU).
+
+    in_lwe: [batch][n_inputs][n+1] int32 on rank `src`; the other ranks pass None.  Rank `src` deals out contiguous slices
+    (shard_slice; host-side scatter, there is no device collective on the data path), every rank evaluates its own slice
+    on its own context -- independent expressions, nothing exchanged -- and rank `src` receives the results concatenated in
+    batch order ([batch][n_outputs][n+1]); the others return None.  dist None: ctx.eval_batch.  A rank whose slice is empty
+    (batch < world) evaluates nothing.  The output does not depend on the number of ranks."""
+    if dist is None:
+        return ctx.eval_batch(kind, bits, in_lwe, stats)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    parts = None
+    if rank == src:
+        in_lwe = np.ascontiguousarray(in_lwe, dtype=np.int32)
+        parts = [in_lwe[shard_slice(in_lwe.shape[0], r, world)] for r in range(world)]
+    mine = [None]
+    dist.scatter_object_list(mine, parts, src=src)
+    mine = mine[0]
+    local = ctx.eval_batch(kind, bits, mine, stats) if mine.shape[0] else None
+    objs = [None] * world if rank == src else None
+    dist.gather_object(local, objs, dst=src)
+    if rank != src:
+        return None
+    return np.concatenate([o for o in objs if o is not None], axis=0)

@@ -186,6 +186,15 @@ int ieache_ctx_force_generic(ieache_ctx* ctx, int on);
  * `x AND 0` on the zero rows of its shift-add multipliers (SURVEY App. C note); the folded circuit
  * decrypts to the same bits with fewer bootstraps but is NOT the reference's ciphertext. */
 int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value);
+/* "overlap" (0/1, default 1; IEACHE_OVERLAP): the context issues its launches on two streams.  A circuit over a batch whose
+ * mean level holds at least "pipe_min" gate instances (default 8 per CU) runs as two pipelines, each taking half of the
+ * EXPRESSIONS through every level with no join in between; otherwise a level of at least "overlap_min" gate instances
+ * (default 16 per CU) is issued as two halves with a join before the next level.  Same output bits either way; 0 = one
+ * stream, the mode per-kernel timings are taken in (csrc/evaluator.h).  "wg_gates" (0 = by launch size, 1 .. 4): gate
+ * instances per workgroup of the one-wave-per-gate kernels.
+ * ieache_ctx_get_option: the current value of any option above, or of the read-only figures "cus" (compute units of the
+ * context's device), "resident_gates", "overlapped_levels", "pipelined_evals", "staging_allocations". */
+int ieache_ctx_get_option(const ieache_ctx* ctx, const char* name, int64_t* value);
 const char* ieache_ctx_kernel_variant(const ieache_ctx* ctx);
 /* Name of the blind-rotation kernel a launch of `gates` gate instances takes under the context's
  * current options (launch sizes select different kernels: docs in csrc/blind_rotate_w64.h).  Like
@@ -305,6 +314,18 @@ int ieache_verif(const char* secret_key_path, const char* nbit_key_path, const c
  * SIGINT/SIGTERM.  Returns the number of requests served or IEACHE_E*. */
 int64_t ieache_serve(const char* socket_path, const char* cloud_key_path, const char* nbit_key_path, int device,
                      int64_t max_requests);
+/* The same daemon on several GPUs of the node (cloudd --devices 0,1,... or IEACHE_DEVICES=0,1,...): one evaluator per listed
+ * device, the cloud key read once and uploaded to each.  A round's same-circuit requests (batch window above) are cut into
+ * contiguous slices, one per device -- ieache_shard_slice's rule, the one bench.py and ie-ache_amd/parallel.py apply across
+ * ranks (independent expressions, no exchange between GPUs) --, evaluated concurrently and answered in request
+ * order; a lone request runs on devices[0].  A device may be listed twice (two contexts on one card).  Answers do not
+ * depend on the device list: every expression goes through the same circuit and kernels.
+ * Reference caller served: dragonfly_cipher_cloud.py:1233 (one ./cloud per operator; batches come from concurrent clients). */
+int64_t ieache_serve_devices(const char* socket_path, const char* cloud_key_path, const char* nbit_key_path, const int* devices,
+                             int n_devices, int64_t max_requests);
+/* slice [*first, *first + *count) of `total` independent expressions that part `part` of `parts` takes: contiguous, sizes
+ * differing by at most one, the first total % parts parts one longer */
+int ieache_shard_slice(size_t total, size_t parts, size_t part, size_t* first, size_t* count);
 /* clients: return what main() of cloud.c would (0 / 126) or IEACHE_E*;
  * IEACHE_ENODEV when no daemon listens on socket_path */
 int ieache_client_ping(const char* socket_path);

@@ -157,3 +157,39 @@ def test_cloudd_fails_loudly_without_a_gpu(ia, tmp_path):
     else:
         assert r.returncode == 0 and b"served 0 requests" in r.stdout
     assert not (tmp_path / "s").exists()
+
+
+def test_device_list_parsing_and_stats_format(ia, tmp_path, monkeypatch):
+    """cloudd --devices / IEACHE_DEVICES take a comma-separated list (anything else: exit 2 before any key is read); the client
+    parses the STATS line with its per-device job counts; spawn() passes the list on."""
+    from ieache_amd import daemon
+    exe = os.path.join(os.path.dirname(ia.library_path()), "cloudd")
+    for bad in ("0,x", "", "0;1", "-1", "0,,1"):
+        r = subprocess.run([exe, "--devices", bad, "--key", str(tmp_path / "missing.key")], capture_output=True, timeout=60)
+        assert r.returncode == 2 and b"--devices" in r.stderr, bad
+    r = subprocess.run([exe, "--key", str(tmp_path / "missing.key")], env=dict(os.environ, IEACHE_DEVICES="zero"), capture_output=True, timeout=60)
+    assert r.returncode == 2 and b"IEACHE_DEVICES" in r.stderr
+    # a well-formed list gets as far as the key file (missing here): exit 1, the key's name in the message
+    r = subprocess.run([exe, "--devices", "0,0,1", "--socket", str(tmp_path / "s"), "--key", str(tmp_path / "missing.key")], capture_output=True, timeout=60)
+    assert r.returncode == 1 and b"missing.key" in r.stderr
+    st = daemon.parse_stats("evaluations=3 batched_requests=8 largest_batch=6 devices=2 sharded_evaluations=1 device_jobs=5,3")
+    assert st == {"evaluations": 3, "batched_requests": 8, "largest_batch": 6, "devices": 2, "sharded_evaluations": 1, "device_jobs": [5, 3]}
+    seen = {}
+
+    class FakeProc:
+        returncode = 3
+
+        def __init__(self, cmd, env=None):
+            seen["cmd"] = cmd
+
+        def poll(self):
+            return 3
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    with pytest.raises(daemon.DaemonError):
+        daemon.spawn(tmp_path / "x.sock", tmp_path / "cloud.key", devices=(0, 1, 2, 3, 4, 5, 6, 7), batch_window_ms=50)
+    cmd = seen["cmd"]
+    assert cmd[cmd.index("--devices") + 1] == "0,1,2,3,4,5,6,7" and "--device" not in cmd and "--batch-window-ms" in cmd
+    with pytest.raises(daemon.DaemonError):
+        daemon.spawn(tmp_path / "x.sock", tmp_path / "cloud.key", device=2)
+    assert seen["cmd"][seen["cmd"].index("--device") + 1] == "2" and "--devices" not in seen["cmd"]

@@ -33,8 +33,8 @@ def test_blind_rotate_stage_bit_exact(gpu_ctx, n, N):
             assert np.array_equal(ref, acc[i]), (steps, i)
 
 
-@pytest.mark.parametrize("n,N", [(5, 64), (16, 1024), (630, 1024)])
-def test_keyswitch_stage_bit_exact(gpu_ctx, n, N):
+@pytest.mark.parametrize("n,N", [(5, 64), (8, 256), (16, 1024), (630, 1024)])
+def test_keyswitch_stage_bit_exact(ia, gpu_ctx, n, N):
     kb, ctx = gpu_ctx(n, N)
     rng = np.random.default_rng(0)
     u = rng.integers(-2 ** 31, 2 ** 31, size=(5, N + 1), dtype=np.int64).astype(np.int32)
@@ -55,9 +55,16 @@ def test_keyswitch_stage_bit_exact(gpu_ctx, n, N):
         ctx.set_option("ks_sliced_min", 576)
     # the int8 MFMA product (launches of >= 64 gates) on the same edge rows, against the oracle: every K split
     ctx.set_option("ks_mfma_min", 1)
-    for split in (0, 1, 2, 4, 8):
+    # the product's loop takes two digit groups (eight coefficients of B fragments) per trip: a split must hold whole trips.
+    # The largest such split is N / 8 -- correct -- and the next power of two (one group per split) is refused when set
+    largest = min(64, N // 8)
+    for split in (0, 1, 2, 4, 8, largest):
         ctx.set_option("ks_mfma_split", split)
         assert np.array_equal(ctx.debug_keyswitch(u), out), split
+    if 2 * largest <= 64:
+        with pytest.raises(ia.IeacheError):
+            ctx.set_option("ks_mfma_split", 2 * largest)
+        assert ctx.get_option("ks_mfma_split") == largest  # a refused value changes nothing
     ctx.set_option("ks_mfma_split", 0)
     ctx.set_option("ks_mfma_min", 64)
 
@@ -860,6 +867,118 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
         ctx.set_option("no_such_knob", 1)
 
 
+def test_level_overlap_on_two_streams_same_bits(ia, gpu_ctx):
+    """Option "overlap": a level of at least overlap_min gate instances is issued as pieces alternating between two streams of the
+    context (own scratch per stream, one key copy, event join before the next level).  Same launches on the same gate instances:
+    every output word equals the one-stream run's and the oracle's -- flat gates and circuits, odd sizes, pieces smaller than
+    half a level (chunk), an audit on every launch of both streams."""
+    kb, ctx = gpu_ctx(16, 1024)
+    assert ctx.get_option("overlap") == 1 and ctx.get_option("overlap_min") == 16 * ctx.get_option("cus")
+    rng = np.random.default_rng(77)
+    bits = rng.integers(0, 2, size=(2, 4999)).astype(np.uint8)
+    a, b = kb.enc(bits[0], 31), kb.enc(bits[1], 32)
+    ctx.set_option("overlap", 0)
+    ref = ctx.gates(ia.GATE_XOR, a, b)
+    assert np.array_equal(kb.dec(ref), bits[0] ^ bits[1])
+    for i in (0, 2499, 2500, 4998):
+        assert np.array_equal(kb.ck.gate("xor", a[i], b[i]), ref[i])
+    ctx.set_option("overlap", 1)
+    audit0 = ctx.fft_audit()  # counts over the (shared) context's life
+    try:
+        for omin, chunk, audit in ((4096, 65536, 64), (2, 65536, 1), (1000, 700, 64), (2, 1, 0)):
+            ctx.set_option("overlap_min", omin)
+            ctx.set_chunk(chunk)
+            ctx.set_option("fft_audit", audit)
+            n = 4999 if chunk > 1 else 37  # chunk 1: one gate per piece, 37 pieces on alternating streams
+            before = ctx.get_option("overlapped_levels")
+            st = ia.Stats()
+            out = ctx.gates(ia.GATE_XOR, a[:n], b[:n], st)
+            assert np.array_equal(out, ref[:n]), (omin, chunk)
+            assert ctx.get_option("overlapped_levels") == before + 1 and st.bootstraps == n
+            pieces = -(-n // min(chunk, (((n + 1) // 2) + 3) & ~3))
+            assert st.chunks == pieces and st.keyswitch_launches == pieces, (st.chunks, pieces)
+        audit1 = ctx.fft_audit()
+        assert audit1["mismatches"] == audit0["mismatches"] and audit1["audits"] >= audit0["audits"] + 2  # both streams' launches audited
+        # below overlap_min nothing changes: one stream, one piece
+        ctx.set_option("overlap_min", 5000)
+        ctx.set_chunk(65536)
+        before = ctx.get_option("overlapped_levels")
+        st = ia.Stats()
+        assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b, st), ref) and st.chunks == 1
+        assert ctx.get_option("overlapped_levels") == before
+        # a circuit: every level of add16 x 40 (40 or 80 gate instances) on two streams, against the sequential oracle
+        vals = [(int(x), int(y)) for x, y in rng.integers(0, 1 << 16, size=(40, 2))]
+        inp = _inputs(kb, 1, 16, vals, 9)
+        ctx.set_option("overlap", 0)
+        cref = ctx.eval_batch(1, 16, inp)
+        ctx.set_option("overlap", 1)
+        ctx.set_option("overlap_min", 40)
+        before = ctx.get_option("overlapped_levels")
+        st = ia.Stats()
+        cout = ctx.eval_batch(1, 16, inp, st)
+        assert np.array_equal(cout, cref) and ctx.get_option("overlapped_levels") == before + 48 and st.chunks == 96
+        s, _ = kb.ck.add(inp[7, :16], inp[7, 16:32], inp[7, 32:33], 16)
+        assert np.array_equal(s, cout[7])
+        assert ctx.get_option("pipelined_evals") == 0  # 80 x 40 gate instances over 48 levels is below pipe_min (8 per CU and level)
+        # ... and as two PIPELINES: the batch cut into two halves of expressions, each through all 48 levels on its own stream with
+        # no join in between ("pipe_min" lowered so that this small batch qualifies); odd batches, two expressions, chunked pieces
+        ctx.set_option("pipe_min", 1)
+        for nb, chunk in ((40, 65536), (39, 65536), (2, 65536), (40, 7)):
+            ctx.set_chunk(chunk)
+            before, lv = ctx.get_option("pipelined_evals"), ctx.get_option("overlapped_levels")
+            st = ia.Stats()
+            pout = ctx.eval_batch(1, 16, inp[:nb], st)
+            assert np.array_equal(pout, cref[:nb]), (nb, chunk)
+            assert ctx.get_option("pipelined_evals") == before + 1 and ctx.get_option("overlapped_levels") == lv
+            assert st.levels == 48 and st.bootstraps == 80 * nb and st.chunks >= 96
+        ctx.set_chunk(65536)
+        before = ctx.get_option("pipelined_evals")
+        assert np.array_equal(ctx.eval_batch(1, 16, inp[:1]), cref[:1]) and ctx.get_option("pipelined_evals") == before  # one expression: one stream
+        ctx.set_option("exact_fft", 1)
+        assert np.array_equal(ctx.eval_batch(1, 16, inp), cref) and ctx.get_option("pipelined_evals") == before + 1
+        ctx.set_option("exact_fft", 0)
+        ctx.set_option("pipe_min", 8 * ctx.get_option("cus"))
+        # the exact (two-limb) kernels and the MUX gate (never overlapped: its two rotations feed one key switch) are unaffected
+        ctx.set_option("exact_fft", 1)
+        assert np.array_equal(ctx.eval_batch(1, 16, inp), cref)
+        ctx.set_option("exact_fft", 0)
+        c = kb.enc(rng.integers(0, 2, size=100).astype(np.uint8), 33)
+        m1 = ctx.mux(a[:100], b[:100], c)
+        ctx.set_option("overlap", 0)
+        assert np.array_equal(ctx.mux(a[:100], b[:100], c), m1)
+    finally:
+        ctx.set_option("overlap", 1)
+        ctx.set_option("overlap_min", 16 * ctx.get_option("cus"))
+        ctx.set_option("pipe_min", 8 * ctx.get_option("cus"))
+        ctx.set_chunk(65536)
+        ctx.set_option("fft_audit", 64)
+    assert not ctx.set_option_ok("overlap", 2) and not ctx.set_option_ok("overlap_min", 1)
+
+
+def test_level_overlap_at_product_parameters(ia, gpu_ctx):
+    """n=630: 4 608 XOR gates as one launch (overlap 0) and as two halves of 2 304 on two streams: identical words, oracle on samples,
+    and the exact two-limb kernels under overlap as well."""
+    kb, ctx = gpu_ctx(630, 1024)
+    rng = np.random.default_rng(78)
+    bits = rng.integers(0, 2, size=(2, 4608)).astype(np.uint8)
+    a, b = kb.enc(bits[0], 41), kb.enc(bits[1], 42)
+    ctx.set_option("overlap", 0)
+    ref = ctx.gates(ia.GATE_XOR, a, b)
+    ctx.set_option("overlap", 1)
+    before = ctx.get_option("overlapped_levels")
+    st = ia.Stats()
+    out = ctx.gates(ia.GATE_XOR, a, b, st)
+    assert ctx.get_option("overlapped_levels") == before + 1 and st.chunks == 2
+    assert np.array_equal(out, ref) and np.array_equal(kb.dec(out), bits[0] ^ bits[1])
+    for i in (0, 2303, 2304, 4607):
+        assert np.array_equal(kb.ck.gate("xor", a[i], b[i]), out[i]), i
+    ctx.set_option("exact_fft", 1)
+    try:
+        assert np.array_equal(ctx.gates(ia.GATE_XOR, a, b), ref)
+    finally:
+        ctx.set_option("exact_fft", 0)
+
+
 def test_edge_cases_empty_batch_and_chunking(ia, gpu_ctx):
     kb, ctx = gpu_ctx(4, 1024)
     info = ia.circuit_info(ia.CIRC_ADD, 32)
@@ -1267,10 +1386,14 @@ def test_resident_key_daemon(ia, O, tmp_path):
                 proc.kill()
 
 
-def test_daemon_batches_concurrent_requests(ia, O, tmp_path):
+@pytest.mark.parametrize("devices", [None, (0, 0)])
+def test_daemon_batches_concurrent_requests(ia, O, tmp_path, devices):
     """cloudd --batch-window-ms: requests of several clients that arrive together are answered together, those asking
     for the same circuit as ONE level-batched evaluation.  Every client still gets exactly its own answer: the value
-    samples equal a one-at-a-time run (and the oracle) bit for bit."""
+    samples equal a one-at-a-time run (and the oracle) bit for bit.
+    devices (0, 0): cloudd --devices 0,0 -- two evaluators (two contexts on this box's one card, the way an 8-GPU node would
+    list 0,...,7); the round's same-circuit jobs are cut into contiguous slices, one per evaluator, run concurrently and
+    answered in request order: same answers, bit for bit."""
     import signal
     import threading
     from ieache_amd import daemon, tools
@@ -1291,7 +1414,7 @@ def test_daemon_batches_concurrent_requests(ia, O, tmp_path):
         tools.alice(d, 0, bits, b, seed=200 + i, append=True)
         jobs.append((d, operator, bits, a, b))
     sock = tmp_path / "cloudd.sock"
-    proc = daemon.spawn(sock, tmp_path / "cloud.key", batch_window_ms=400, max_batch=64)
+    proc = daemon.spawn(sock, tmp_path / "cloud.key", batch_window_ms=400, max_batch=64, devices=devices)
     try:
         results = [None] * 8
         barrier = threading.Barrier(8)
@@ -1314,6 +1437,11 @@ def test_daemon_batches_concurrent_requests(ia, O, tmp_path):
             t.join(timeout=300)
         st = daemon.stats(sock)
         assert st["batched_requests"] == 8 and st["largest_batch"] >= 2 and st["evaluations"] < 8, st
+        assert st["devices"] == (len(devices) if devices else 1) and sum(st["device_jobs"]) == 8, st
+        if devices:  # the six additions (or whatever part of them shared a round) went to both evaluators
+            assert st["sharded_evaluations"] >= 1 and min(st["device_jobs"]) >= 1, st
+        else:
+            assert st["sharded_evaluations"] == 0 and st["device_jobs"] == [8], st
         together = 0
         for i, (d, operator, bits, a, b) in enumerate(jobs):
             rc, log = results[i]
@@ -1328,6 +1456,8 @@ def test_daemon_batches_concurrent_requests(ia, O, tmp_path):
             ans = tools.read_samples(d / "answer.data", p.n).reshape(11, 32, p.n + 1)
             assert rc2 == 0 and np.array_equal(ans[2:], ref), i
         assert together >= 2
+        if devices:
+            assert any("on 2 devices" in results[i][1] for i in range(8))
         # failures inside a round are answered individually and do not take the round down
         bad = threading.Thread(target=lambda: results.__setitem__(0, daemon.run_data(sock, 1, b"short")))
         good = threading.Thread(target=lambda: results.__setitem__(1, daemon.run_data(sock, 1, (jobs[1][0] / "cloud.data").read_bytes())))

@@ -111,3 +111,79 @@ def test_single_rank_process_group_option(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=tmp_path,
                        env=dict(env, IEACHE_DIST_SINGLE="1"))
     assert r.returncode == 0 and "single-rank ok" in r.stdout, r.stderr[-2000:]
+
+
+SHARDED_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    from ieache_amd import parallel
+    rank, world, local_rank, dist = parallel.init_distributed("gloo")
+
+    class StandIn:  # what parallel.eval_batch_sharded needs of a Context; stamps each output row with the rank that made it
+        calls = 0
+        def eval_batch(self, kind, bits, in_lwe, stats=None):
+            StandIn.calls += 1
+            assert in_lwe.dtype == np.int32 and in_lwe.ndim == 3
+            out = in_lwe[:, :2, :] * 3 + kind
+            out[:, :, -1] = rank
+            return out
+
+    ctx = StandIn()
+    for total in (11, 1):   # 11: slices of 6 and 5 (world 2) / 4, 4, 3 (world 3); 1: the other ranks' slices are empty
+        full = np.arange(total * 5 * 4, dtype=np.int32).reshape(total, 5, 4) if rank == 0 else None
+        got = parallel.eval_batch_sharded(ctx, 7, 16, full, dist)
+        if rank == 0:
+            exp = full[:, :2, :] * 3 + 7
+            assert got.shape == exp.shape and np.array_equal(got[:, :, :-1], exp[:, :, :-1])
+            owners = [r for r in range(world) for _ in range(parallel.shard_slice(total, r, world).stop - parallel.shard_slice(total, r, world).start)]
+            assert got[:, 0, -1].tolist() == owners, (got[:, 0, -1].tolist(), owners)
+        else:
+            assert got is None
+    assert StandIn.calls == (2 if rank == 0 else 1)   # an empty slice evaluates nothing
+    if rank == 0:
+        print("SHARDED_OK", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""") % ROOT
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_eval_batch_sharded_deals_slices_and_reassembles_in_order(tmp_path, world):
+    """parallel.eval_batch_sharded on gloo ranks with a stand-in context: contiguous slices out, results back in batch order."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "sharded_worker.py"
+    script.write_text(SHARDED_WORKER)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, _ = pr.communicate()
+        outs.append(out)
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
+    assert "SHARDED_OK" in outs[0]
+
+
+def test_native_shard_rule_matches_the_python_one(ia):
+    """The daemon's per-device slicing (ieache_shard_slice = daemon_shard, csrc/daemon.cpp) is parallel.shard_slice."""
+    import ctypes as C
+    from ieache_amd.parallel import shard_slice
+    L = ia.lib()
+    for total in (0, 1, 5, 16, 17, 255, 1024):
+        for parts in (1, 2, 3, 8):
+            for part in range(parts):
+                first, count = C.c_size_t(0), C.c_size_t(0)
+                assert L.ieache_shard_slice(total, parts, part, C.byref(first), C.byref(count)) == 0
+                sl = shard_slice(total, part, parts)
+                assert (first.value, count.value) == (sl.start, sl.stop - sl.start)
+    first, count = C.c_size_t(0), C.c_size_t(0)
+    assert L.ieache_shard_slice(4, 2, 2, C.byref(first), C.byref(count)) < 0 and L.ieache_shard_slice(4, 0, 0, C.byref(first), C.byref(count)) < 0
