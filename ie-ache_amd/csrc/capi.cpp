@@ -25,6 +25,8 @@ using namespace ieache;
 struct ieache_ctx {
     std::unique_ptr<Evaluator> eval;
     std::map<std::tuple<int, int, bool, int>, Circuit> circuits;  // (kind, bits, folded, level cap)
+    std::map<std::tuple<int, int, bool, int>, uint64_t> circuit_used;  // last use of each level-capped variant (LRU order)
+    uint64_t circuit_clock = 0;
     std::string variant;
     bool fold = false;           // "fold_constants"
     bool level_quantum = true;   // "level_quantum": batch-aware level widths for the slack-balanced circuits
@@ -107,17 +109,32 @@ const Circuit* get_circuit(ieache_ctx* ctx, int kind, int bits, size_t batch = 0
     auto fetch = [&](int cap) -> const Circuit* {
         auto key = std::make_tuple(kind, bits, ctx->fold, cap);
         auto it = ctx->circuits.find(key);
-        if (it != ctx->circuits.end()) return &it->second;
+        if (it != ctx->circuits.end()) {
+            if (cap != 0) ctx->circuit_used[key] = ++ctx->circuit_clock;
+            return &it->second;
+        }
         Circuit c;
         if (!build_circuit(kind, bits, &c, true, ctx->fold, cap)) return nullptr;
-        if (cap != 0) {  // bounded: one level-capped variant per (kind, width, folding) -- the cap follows the batch size
-            for (auto jt = ctx->circuits.begin(); jt != ctx->circuits.end();) {
-                const auto& k = jt->first;
-                if (std::get<0>(k) == kind && std::get<1>(k) == bits && std::get<2>(k) == ctx->fold && std::get<3>(k) != 0)
-                    jt = ctx->circuits.erase(jt);
-                else
-                    ++jt;
+        if (cap != 0) {
+            // Bounded: the cap follows the batch size (and the kernel family: "exact_fft" changes the resident-gate count), and
+            // a variant of the wide multipliers is several MB, so at most kCappedVariants per (kind, width, folding) are kept.
+            // The least recently used one goes, and only once the new circuit exists -- a caller that alternates between two
+            // batch sizes or toggles exact_fft per call (bench.py's exact leg, the audit flows) rebuilds nothing.
+            constexpr size_t kCappedVariants = 3;
+            std::vector<std::tuple<int, int, bool, int>> mine;
+            for (const auto& kv : ctx->circuits) {
+                const auto& k = kv.first;
+                if (std::get<0>(k) == kind && std::get<1>(k) == bits && std::get<2>(k) == ctx->fold && std::get<3>(k) != 0) mine.push_back(k);
             }
+            while (mine.size() >= kCappedVariants) {
+                size_t oldest = 0;
+                for (size_t i = 1; i < mine.size(); i++)
+                    if (ctx->circuit_used[mine[i]] < ctx->circuit_used[mine[oldest]]) oldest = i;
+                ctx->circuits.erase(mine[oldest]);
+                ctx->circuit_used.erase(mine[oldest]);
+                mine.erase(mine.begin() + oldest);
+            }
+            ctx->circuit_used[key] = ++ctx->circuit_clock;
         }
         return &ctx->circuits.emplace(key, std::move(c)).first->second;
     };

@@ -772,11 +772,14 @@ def test_kernel_variants_agree_bit_for_bit(ia, gpu_ctx):
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
     # ... which kernel by launch size: 2L waves per gate up to one per CU, two waves per gate up to four per CU, one wave per
     # gate above ("exact_one_wave_min" moves that boundary)
-    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (200, 300, 1024, 1025)] == \
+    cus = ctx.get_option("cus")                            # 256 on an MI355X: the boundaries below are per CU
+    one_wave_min = ctx.get_option("exact_one_wave_min")
+    assert one_wave_min == 4 * cus + 1
+    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (cus - 56, cus + 44, 4 * cus, 4 * cus + 1)] == \
         ["k_blind_rotate_wide", "k_blind_rotate_w2", "k_blind_rotate_w2", "k_blind_rotate_x1"]
     ctx.set_option("exact_one_wave_min", 0)
     assert ctx.kernel_for_launch(300).startswith("k_blind_rotate_x1") and np.array_equal(ctx.gates(ia.GATE_AND, a[:300], b[:300]), ref[:300])
-    ctx.set_option("exact_one_wave_min", 1025)
+    ctx.set_option("exact_one_wave_min", one_wave_min)
     ctx.set_option("exact_fft", 0)
     ctx.set_option("fft_guard_inject", 1)                  # a tripped guard makes the call repeat itself on the two-limb kernel
     assert np.array_equal(ctx.gates(ia.GATE_AND, a, b), ref)
@@ -1179,6 +1182,24 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
     assert np.array_equal(ref, mid[:640])
     assert np.array_equal(ref[:400], four) and np.array_equal(ref[:200], narrow)
     assert np.array_equal(ref, results[0][0][:640])      # and the wide-launch kernel's first level
+    # round 5: the one-wave-per-gate kernels built for 1 .. 4 gates per workgroup ("wg_gates"; by default three while a launch
+    # holds at most six gates per CU), one-limb (k_blind_rotate_w1b) and two-limb (k_blind_rotate_x1): 1 400 gates of the same
+    # level against the oracle's 640 and, beyond them, against the 16 384-gate launch above; ragged last workgroups (1 400 = 3 x 466 + 2)
+    cus = ctx.get_option("cus")
+    assert ctx.get_option("wg_gates") == 0 and ctx.get_option("wg3_max") == 6 * cus
+    for exact in (0, 1):
+        ctx.set_option("exact_fft", exact)
+        ctx.set_option("two_wave_max", 0)                  # one wave per gate at this size (the default below 5 per CU is two)
+        assert ctx.kernel_for_launch(1400).split("<")[0] == ("k_blind_rotate_x1" if exact else "k_blind_rotate_w1b")
+        for wg in (0, 1, 2, 3, 4):
+            ctx.set_option("wg_gates", wg)
+            o = ctx.gates(ia.GATE_XOR, a[:1400], b[:1400])
+            assert np.array_equal(o[:640], ref) and np.array_equal(o, results[1][0][:1400]), (exact, wg)
+        ctx.set_option("wg_gates", 0)
+        ctx.set_option("two_wave_max", 5 * cus)
+    ctx.set_option("exact_fft", 0)
+    with pytest.raises(ia.IeacheError):
+        ctx.set_option("wg_gates", 5)
 
 
 def test_full_config_add16_batch4096_decrypts(ia, gpu_ctx):
@@ -1297,9 +1318,14 @@ def test_old_libtfhe_parameter_set_on_fast_kernel(ia, gpu_ctx):
     assert np.array_equal(kb.dec(wout), wide_bits[0] & wide_bits[1])
     for i in (0, 517, 1100):
         assert np.array_equal(kb.ck.gate("and", wa[i], wb[i]), wout[i]), i
+    for wg in (1, 2, 3, 4):                                # its builds for 1 .. 4 gates per workgroup (ragged last workgroups)
+        ctx.set_option("wg_gates", wg)
+        assert np.array_equal(ctx.gates(ia.GATE_AND, wa, wb), wout), wg
+    ctx.set_option("wg_gates", 0)
+    one_wave_min = ctx.get_option("exact_one_wave_min")
     ctx.set_option("exact_one_wave_min", 1 << 40)
     assert ctx.kernel_for_launch(1101) == "k_blind_rotate_w2<2,10>" and np.array_equal(ctx.gates(ia.GATE_AND, wa, wb), wout)
-    ctx.set_option("exact_one_wave_min", 1025)
+    ctx.set_option("exact_one_wave_min", one_wave_min)
     x = kb.enc([1, 0, 1], 63)
     acc = ctx.debug_blind_rotate(x, 3)
     for i in range(3):
