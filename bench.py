@@ -337,15 +337,15 @@ def compact_line(full, details_path):
     return line
 
 
-def write_details(full):
-    """bench_details.json next to the script (or in $TMPDIR when the tree is read-only): the full record the line summarises"""
+def write_details(full, path=None):
+    """The full record the line summarises: `path` (--details), else bench_details.json next to the script (or in $TMPDIR when the
+    tree is read-only).  Returns the name the line carries in `details`."""
     import tempfile
-    for d in (ROOT, tempfile.gettempdir()):
-        path = os.path.join(d, DETAILS_FILE)
+    for cand in ([path] if path else [os.path.join(ROOT, DETAILS_FILE), os.path.join(tempfile.gettempdir(), DETAILS_FILE)]):
         try:
-            with open(path, "w") as f:
+            with open(cand, "w") as f:
                 json.dump(full, f, indent=1)
-            return DETAILS_FILE if d == ROOT else path
+            return DETAILS_FILE if cand == os.path.join(ROOT, DETAILS_FILE) else cand
         except OSError:
             continue
     return None
@@ -499,6 +499,7 @@ def main():
                     help="a leg is skipped (and named in `skipped_legs`) when the run has already taken this many seconds minus the leg's estimate")
     ap.add_argument("--metric-passes", type=int, default=2,
                     help="timed passes of the mul32 leg (the config BASELINE.json quotes its metric on); the line reports each and their spread")
+    ap.add_argument("--details", default=None, help="where the full record goes (default: bench_details.json next to this script)")
     ap.add_argument("--roofline-steps", type=int, default=3,
                     help="steps of the primary batch run with every launch on one stream (overlap = 0) after the timed region, for the per-kernel roofline figures")
     ap.add_argument("--exact-leg", default="on", choices=["on", "off"],
@@ -748,7 +749,7 @@ def main():
             out["mul32_per_s"] = batch * args.steps * world / elapsed
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, keys, args.cpu_seconds)
-        print(compact_line(out, write_details(out)), flush=True)
+        print(compact_line(out, write_details(out, args.details)), flush=True)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -1537,23 +1537,31 @@ def test_bench_two_rank_flow_on_one_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--batch", "48", "--backend", "gloo", "--no-cpu-baseline", "--legs", "mul32,muladd64", "--mul32-batch", "6",
-           "--muladd64-batch", "2", "--extras"]
+           "--muladd64-batch", "2", "--extras", "--details", str(tmp_path / "details.json")]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path,
                        env=dict(env, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 6000, r.stdout[-2000:]      # ONE compact line (bench.LINE_LIMIT) ...
+    line = json.loads(lines[0])
+    out = json.load(open(tmp_path / "details.json"))                        # ... and the full record it summarises
+    assert line["details"] == str(tmp_path / "details.json") and line["value"] == pytest.approx(out["value"], rel=1e-5)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and "cpu_baseline" not in line
+    assert line["config"]["batch_per_gpu"] == 48 and line["config"]["parallelism"] == "batch-sharded x2"
+    assert line["config"]["collective_backend"] == "gloo" and len(line["config"]["per_rank_gate_ops_per_s"]) == 2
+    lrf = line["roofline"]
+    assert lrf["bound"] == "fp64_valu" and 0 < lrf["frac"] < 1 and abs(lrf["achieved"] / lrf["peak"] - lrf["frac"]) < 1e-4 and "note" not in lrf
+    assert line["mul32"]["batch_per_gpu"] == 6 and line["mul32_per_s"] > 0 and line["muladd64"]["roofline_frac"] > 0 and "mul128" not in line
+    assert line["mul32"]["folded"]["mul32_per_s"] > 0 and line["mul32"]["carry_save"]["mul32_per_s"] > 0
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["config"]["batch_per_gpu"] == 48 and out["config"]["parallelism"] == "batch-sharded x2"
     rf = out["roofline"]
     assert "cpu_baseline" not in out and rf["bound"] == "fp64_valu" and 0 < rf["frac"] == rf["frac_algorithmic_flops"] < 1
     assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-9 and rf["algorithmic_flops_per_gate"] == 630 * 233472
-    assert out["config"]["collective_backend"] == "gloo" and len(out["config"]["per_rank_gate_ops_per_s"]) == 2
     # the other legs ran on both ranks too (their passes contain barriers: a rank skipping one would hang the other)
     m = out["mul32"]
     assert m["batch_per_gpu"] == 6 and len(m["per_rank_gate_ops_per_s"]) == 2 and m["mul32_per_s"] == out["mul32_per_s"] > 0
+    assert m["passes"] == 2 and len(m["per_pass_gate_ops_per_s"]) == 2     # the metric's own leg is timed twice
     assert m["folded"]["executed_bootstraps_per_expr"] == 7568 and m["carry_save"]["levels"] == 37
     ma = out["muladd64"]
     assert ma["batch_per_gpu"] == 2 and ma["bootstraps_per_expr"] == 35936 and ma["roofline"]["frac"] > 0 and "mul128" not in out
@@ -1571,7 +1579,8 @@ def test_bench_default_command_shape_with_three_ranks_on_one_gpu(tmp_path):
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--backend", "gloo", "--batch", "64", "--legs",
-           "mul32,muladd64,mul128", "--mul32-batch", "8", "--muladd64-batch", "4", "--mul128-batch", "2", "--no-cpu-baseline"]
+           "mul32,muladd64,mul128", "--mul32-batch", "8", "--muladd64-batch", "4", "--mul128-batch", "2", "--no-cpu-baseline",
+           "--details", str(tmp_path / "details.json")]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp_path,
@@ -1579,8 +1588,13 @@ def test_bench_default_command_shape_with_three_ranks_on_one_gpu(tmp_path):
     wall = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 6000, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "metric_leg", "exact", "mul32", "muladd64", "mul128"):
+        assert key in line, key
+    assert line["n_gpus"] == 3 and len(line["config"]["per_rank_gate_ops_per_s"]) == 3 and line["exact"]["bit_identical_to_primary_leg"] is True
+    out = json.load(open(tmp_path / "details.json"))
     assert out["n_gpus"] == 3 and out["scaling"] == "weak" and out["value"] > 0 and wall < 300, wall
     cfg = out["config"]
     assert cfg["key_broadcast_s"] > 0 and cfg["collective_backend"] == "gloo" and cfg["parallelism"] == "batch-sharded x3"
@@ -1610,7 +1624,8 @@ def test_bench_collectives_on_rccl_with_one_rank(tmp_path):
     out = json.loads(lines[0])
     cfg = out["config"]
     assert out["n_gpus"] == 1 and cfg["rccl_ranks"] == 1 and cfg["collective_backend"] == "nccl" and cfg["key_broadcast_s"] > 0
-    assert len(cfg["per_rank_gate_ops_per_s"]) == 1 and out["value"] > 0 and out["mul32"]["mul32_per_s"] > 0
+    assert len(cfg["per_rank_gate_ops_per_s"]) == 1 and out["value"] > 0 and out["mul32_per_s"] > 0 and out["mul32"]["expressions_per_s"] > 0
+    assert out["metric_leg"]["passes"] == 2 and len(lines[0]) < 6000
 
 
 def test_output_noise_matches_the_published_variance(ia, gpu_ctx):
