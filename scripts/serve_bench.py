@@ -1,5 +1,6 @@
 """Throughput of the resident-key daemon with and without its batching window (development aid): C concurrent
-clients each send one 32-bit A+B (or A*B) over the socket, at the product parameter set."""
+clients each send one 32-bit A+B (or A*B) over the socket, at the product parameter set.
+DEVICES=0,0 (cloudd --devices): one evaluator per listed device, a round's jobs sliced across them; WINDOWS=100 limits the windows tried."""
 import sys, os, time, tempfile, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ieache_amd as ia
@@ -8,6 +9,8 @@ from ieache_amd import daemon, tools
 d = tempfile.mkdtemp(prefix="ieache_serve_")
 tools.keygen_files(d)
 clients = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+devices = [int(x) for x in os.environ["DEVICES"].split(",")] if os.environ.get("DEVICES") else None
+windows = [int(x) for x in os.environ.get("WINDOWS", "0,100").split(",")]
 for operator, name, f in ((1, "32-bit A+B", lambda a, b: a + b), (4, "32-bit A*B", lambda a, b: a * b)):
     blobs = []
     for i in range(clients):
@@ -18,9 +21,9 @@ for operator, name, f in ((1, "32-bit A+B", lambda a, b: a + b), (4, "32-bit A*B
         tools.alice(sub, 0, 32, 1000 + i, seed=10 + i)
         tools.alice(sub, 0, 32, 7 * i + 1, seed=500 + i, append=True)
         blobs.append((sub, open(os.path.join(sub, "cloud.data"), "rb").read()))
-    for window in (0, 100):
+    for window in windows:
         sock = os.path.join(d, "s%d_%d.sock" % (operator, window))
-        proc = daemon.spawn(sock, os.path.join(d, "cloud.key"), batch_window_ms=window, max_batch=256)
+        proc = daemon.spawn(sock, os.path.join(d, "cloud.key"), batch_window_ms=window, max_batch=256, devices=devices)
         daemon.run_data(sock, operator, blobs[0][1])  # warm-up: circuit build, first launches
         answers = [None] * clients
         go = threading.Barrier(clients + 1)
@@ -43,7 +46,7 @@ for operator, name, f in ((1, "32-bit A+B", lambda a, b: a + b), (4, "32-bit A*B
             open(os.path.join(sub, "answer.data"), "wb").write(ans)
             assert tools.verif_interpret(operator, *tools.verif(sub)) == f(1000 + i, 7 * i + 1)
         st = daemon.stats(sock)
-        print("%s, %d concurrent clients, batching window %3d ms: %.2f s for all (%.1f expressions/s); %s"
-              % (name, clients, window, dt, clients / dt, st), flush=True)
+        print("%s, %d concurrent clients, batching window %3d ms, devices %s: %.2f s for all (%.1f expressions/s); %s"
+              % (name, clients, window, devices or [0], dt, clients / dt, st), flush=True)
         daemon.shutdown(sock)
         proc.wait(timeout=60)

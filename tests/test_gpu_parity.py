@@ -642,6 +642,35 @@ def test_cloud_file_contract_end_to_end(ia, O, tmp_path):
     assert (tmp_path / "averagestandard.txt").exists()  # MUL timing log (cloud.c:2467-2471)
 
 
+def test_host_entry_points_keep_their_staging_rows(ia, gpu_ctx):
+    """The host-buffer entry points (ieache_eval_batch -- what `cloud` and `cloudd` evaluate through --, ieache_gates, ieache_mux)
+    stage operands and results in device rows the evaluator keeps between calls: a warm call (same or smaller size) makes no
+    hipMalloc / hipFree -- each a device-wide synchronisation -- and a larger one grows the rows once.  Results do not depend on
+    what an earlier, larger call left in the rows."""
+    kb, ctx = gpu_ctx(4, 1024)
+    rng = np.random.default_rng(5)
+    vals = [(int(x), int(y)) for x, y in rng.integers(0, 1 << 16, size=(6, 2))]
+    inp = _inputs(kb, 1, 16, vals, 19)
+    big = ctx.eval_batch(1, 16, inp)                      # first use (or growth) of the operand and result rows
+    n0 = ctx.get_option("staging_allocations")
+    assert np.array_equal(ctx.eval_batch(1, 16, inp), big) and ctx.get_option("staging_allocations") == n0
+    small = ctx.eval_batch(1, 16, inp[2:4])               # a smaller batch in the same rows, stale rows behind it
+    assert np.array_equal(small, big[2:4]) and ctx.get_option("staging_allocations") == n0
+    a, b, c = kb.enc(rng.integers(0, 2, size=40), 1), kb.enc(rng.integers(0, 2, size=40), 2), kb.enc(rng.integers(0, 2, size=40), 3)
+    g1, m1 = ctx.gates(ia.GATE_NAND, a, b), ctx.mux(a, b, c)
+    n1 = ctx.get_option("staging_allocations")
+    assert np.array_equal(ctx.gates(ia.GATE_NAND, a, b), g1) and np.array_equal(ctx.mux(a, b, c), m1)
+    assert np.array_equal(ctx.gates(ia.GATE_NAND, a[:7], b[:7]), g1[:7]) and ctx.get_option("staging_allocations") == n1
+    for i in (0, 39):
+        assert np.array_equal(kb.ck.gate("nand", a[i], b[i]), g1[i]) and np.array_equal(kb.ck.mux(a[i], b[i], c[i]), m1[i])
+    inp2 = _inputs(kb, 1, 16, vals * 40, 19)              # 240 expressions: the rows grow (once), results unchanged
+    out2 = ctx.eval_batch(1, 16, inp2)
+    n2 = ctx.get_option("staging_allocations")
+    assert n2 > n1 and np.array_equal(out2[:6], big) and np.array_equal(kb.dec(out2[234:]), kb.dec(big))
+    assert np.array_equal(ctx.eval_batch(1, 16, inp2), out2) and ctx.get_option("staging_allocations") == n2
+    assert ctx.eval_batch(1, 16, inp[:0]).shape[0] == 0
+
+
 def test_cloud_file_contract_at_product_parameters(ia, tmp_path):
     """The ./cloud process contract at n=630 (cloud.c:650-917), through the `cloud` EXECUTABLE: keygen from the documented
     seeds, `alice` twice, operator.txt, ./cloud in that directory, `verif` -- BASELINE configs[0] (16-bit a+b, zero-extended in
