@@ -17,6 +17,7 @@
 #include <memory>
 #include <new>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <tuple>
 
@@ -290,19 +291,25 @@ private:
         outs->assign(jobs.size(), {});
         std::vector<std::vector<std::vector<Torus32>>> part_outs(parts);
         std::vector<std::exception_ptr> errors(parts);
+        auto run_part = [&](size_t d) {
+            try {
+                size_t first = 0, count = 0;
+                daemon_shard(jobs.size(), parts, d, &first, &count);
+                const std::vector<CloudJob*> mine(jobs.begin() + first, jobs.begin() + first + count);
+                cloud_eval_jobs(*evals_[d], mine, &part_outs[d], nullptr);
+            } catch (...) {
+                errors[d] = std::current_exception();
+            }
+        };
         std::vector<std::thread> threads;
-        for (size_t d = 0; d < parts; d++) {
-            threads.emplace_back([&, d] {
-                try {
-                    size_t first = 0, count = 0;
-                    daemon_shard(jobs.size(), parts, d, &first, &count);
-                    const std::vector<CloudJob*> mine(jobs.begin() + first, jobs.begin() + first + count);
-                    cloud_eval_jobs(*evals_[d], mine, &part_outs[d], nullptr);
-                } catch (...) {
-                    errors[d] = std::current_exception();
-                }
-            });
+        for (size_t d = 1; d < parts; d++) {
+            try {
+                threads.emplace_back(run_part, d);
+            } catch (const std::system_error&) {
+                run_part(d);  // no thread to be had: this slice runs here, after the ones already started
+            }
         }
+        run_part(0);  // the first slice on the serving thread itself
         for (std::thread& t : threads) t.join();
         for (const std::exception_ptr& e : errors)
             if (e) std::rethrow_exception(e);
