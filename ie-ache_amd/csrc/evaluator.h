@@ -113,7 +113,8 @@ public:
     //     IEACHE_PIPE_MIN): the batch is cut into two halves of EXPRESSIONS and each half runs through every level on its own
     //     stream -- expressions are independent, so there is one fork after the input copy and one join before the outputs
     //     are gathered, nothing in between (add16 x 4096: +3.5 %, mul32 x 1024: +1.1 %, profiles/r5_overlap_ab.txt);
-    //     kernels are chosen by the gate instances in flight on both streams;
+    //     kernels are chosen by the gate instances in flight on both streams ("pipe_lanes" = 3 or 4 cuts the batch into
+    //     that many pipelines instead: measured no better than two, profiles/r5_overlap_ab.txt);
     //   * otherwise (flat gate calls, narrower circuits) a level of at least "overlap_min" gate instances (default 16 per
     //     CU; IEACHE_OVERLAP_MIN) is cut into pieces of at most half the level that alternate between the two streams, and
     //     the next level starts when both have finished.

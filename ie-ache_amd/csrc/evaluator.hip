@@ -518,6 +518,7 @@ __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus3
 // is overlapped (option "overlap"): then the level's gate instances are cut into pieces that alternate between lane 0 and
 // lane 1 -- a second stream of the SAME context (one copy of the key) with its own extracted-sample rows, blind-rotation
 // state, key-switch digits and audit scratch -- and lane 0 waits for lane 1 before the next level starts.
+constexpr int kMaxLanes = 4;
 struct Lane {
     hipStream_t stream = nullptr;
     Torus32* ext = nullptr;
@@ -532,8 +533,8 @@ struct Lane {
 
 struct Evaluator::Impl {
     Params p;
-    Lane lane[2];
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    Lane lane[kMaxLanes];
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes] = {};  // ev_join[k]: lane k's share of a level / of an evaluation is queued
     // "overlap": 1 = levels of at least overlap_min gate instances are cut in two and issued on two streams (the tail of one
     // piece's launches fills with the other's workgroups, a piece's key switch runs under the next piece's rotation); 0 = one stream
     int32_t overlap = 1;
@@ -545,6 +546,7 @@ struct Evaluator::Impl {
     // level holds at least pipe_min gate instances over the whole batch.  While both pipelines run, a launch shares the
     // chip with the other stream's launch of the same level: kernels are chosen by the gates in flight on BOTH streams.
     int64_t pipe_min = 0;        // set in init(): 8 gates per CU (measured: 11 per CU +2.9 %, 4 per CU -10 %, profiles/r5_overlap_ab.txt)
+    int32_t pipe_lanes = 2;      // pipelines a qualifying evaluation is cut into (2 .. kMaxLanes; "pipe_lanes", IEACHE_PIPE_LANES)
     int32_t concurrency = 1;     // streams issuing launches side by side right now (kernel choice is by cnt x concurrency)
     int64_t pipelined_evals = 0;
     // device rows the host-buffer entry points stage their operands and results in: kept between calls, grown on demand
@@ -638,6 +640,7 @@ void Evaluator::init() {
         d_->overlap_min = 16 * (int64_t)cus;
         d_->pipe_min = 8 * (int64_t)cus;
         if (const char* e = getenv("IEACHE_PIPE_MIN")) d_->pipe_min = atoll(e);
+        if (const char* e = getenv("IEACHE_PIPE_LANES")) d_->pipe_lanes = atoi(e) >= 2 && atoi(e) <= kMaxLanes ? atoi(e) : 2;
         d_->wg3_max = 6 * (int64_t)cus;
         if (const char* e = getenv("IEACHE_WG_GATES")) d_->wg_gates = atoi(e) >= 0 && atoi(e) <= 4 ? atoi(e) : 0;
         if (const char* e = getenv("IEACHE_WG3_MAX")) d_->wg3_max = atoll(e);
@@ -721,7 +724,8 @@ Evaluator::~Evaluator() { destroy(); }
 void Evaluator::destroy() {
     if (!d_) return;
     (void)hipSetDevice(device_);
-    if (d_->lane[1].stream) (void)hipStreamSynchronize(d_->lane[1].stream);
+    for (int k = 1; k < kMaxLanes; k++)
+        if (d_->lane[k].stream) (void)hipStreamSynchronize(d_->lane[k].stream);
     if (stream_) (void)hipStreamSynchronize(stream_);
     (void)hipFree(d_->bkf);
     (void)hipFree(d_->bkf_w64);
@@ -742,8 +746,10 @@ void Evaluator::destroy() {
     (void)hipFree(d_->ext_mux);
     for (Torus32* st : d_->stage) (void)hipFree(st);
     if (d_->ev_fork) (void)hipEventDestroy(d_->ev_fork);
-    if (d_->ev_join) (void)hipEventDestroy(d_->ev_join);
-    if (d_->lane[1].stream) (void)hipStreamDestroy(d_->lane[1].stream);
+    for (int k = 1; k < kMaxLanes; k++) {
+        if (d_->ev_join[k]) (void)hipEventDestroy(d_->ev_join[k]);
+        if (d_->lane[k].stream) (void)hipStreamDestroy(d_->lane[k].stream);
+    }
     (void)hipFree(d_->store);
     (void)hipFree(d_->d_gates);
     (void)hipFree(d_->d_outs);
@@ -820,6 +826,8 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->overlap_min = value;
     } else if (name == "pipe_min" && value >= 0) {
         d_->pipe_min = value;
+    } else if (name == "pipe_lanes" && value >= 2 && value <= kMaxLanes) {
+        d_->pipe_lanes = (int32_t)value;
     } else if (name == "br_wide_max" && value >= 0) {
         d_->br_wide_max = value;
     } else if (name == "br_slice" && value >= 0 && value <= 4096) {  // 0 = by kernel and launch size
@@ -859,6 +867,7 @@ bool Evaluator::get_option(const std::string& name, int64_t* value) const {
     else if (name == "overlap_min") v = d_->overlap_min;
     else if (name == "overlapped_levels") v = d_->overlapped_levels;  // levels issued on two streams so far (a counter)
     else if (name == "pipe_min") v = d_->pipe_min;
+    else if (name == "pipe_lanes") v = d_->pipe_lanes;
     else if (name == "pipelined_evals") v = d_->pipelined_evals;      // circuit evaluations run as two expression-half pipelines so far
     else if (name == "wg_gates") v = d_->wg_gates;
     else if (name == "wg3_max") v = d_->wg3_max;
@@ -1213,10 +1222,24 @@ static void reserve_lane(const Params& p, Evaluator::Impl* d, Lane& ln, size_t n
     if (!d->force_generic_ks && d->ks_mfma_ok && d->ks_limbs && (int64_t)need >= d->ks_mfma_min) reserve_ks_digits(d, ln, (int64_t)need);
 }
 
-static void ensure_second_lane(Evaluator::Impl* d) {
-    if (!d->lane[1].stream) HIP_CHECK(hipStreamCreateWithFlags(&d->lane[1].stream, hipStreamNonBlocking));
+static void ensure_lanes(Evaluator::Impl* d, int lanes) {
     if (!d->ev_fork) HIP_CHECK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
-    if (!d->ev_join) HIP_CHECK(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    for (int k = 1; k < lanes; k++) {
+        if (!d->lane[k].stream) HIP_CHECK(hipStreamCreateWithFlags(&d->lane[k].stream, hipStreamNonBlocking));
+        if (!d->ev_join[k]) HIP_CHECK(hipEventCreateWithFlags(&d->ev_join[k], hipEventDisableTiming));
+    }
+}
+static void ensure_second_lane(Evaluator::Impl* d) { ensure_lanes(d, 2); }
+// fork: lanes 1 .. lanes-1 start when everything queued so far on lane 0 is done; join: lane 0 waits for all of them
+static void fork_lanes(Evaluator::Impl* d, int lanes) {
+    HIP_CHECK(hipEventRecord(d->ev_fork, d->lane[0].stream));
+    for (int k = 1; k < lanes; k++) HIP_CHECK(hipStreamWaitEvent(d->lane[k].stream, d->ev_fork, 0));
+}
+static void join_lanes(Evaluator::Impl* d, int lanes) {
+    for (int k = 1; k < lanes; k++) {
+        HIP_CHECK(hipEventRecord(d->ev_join[k], d->lane[k].stream));
+        HIP_CHECK(hipStreamWaitEvent(d->lane[0].stream, d->ev_join[k], 0));
+    }
 }
 
 // Before an evaluation starts: scratch for its widest launch in one go (the per-launch checks below then find it in place),
@@ -1253,8 +1276,7 @@ static void run_items(const Params& p, Evaluator::Impl* d, WorkDesc W, int64_t i
         reserve_scratch(p, d, &items, 1);
     }
     if (pl.two_lanes) {
-        HIP_CHECK(hipEventRecord(d->ev_fork, d->lane[0].stream));
-        HIP_CHECK(hipStreamWaitEvent(d->lane[1].stream, d->ev_fork, 0));
+        fork_lanes(d, 2);
         d->overlapped_levels++;
     }
     int k = 0;
@@ -1278,10 +1300,7 @@ static void run_items(const Params& p, Evaluator::Impl* d, WorkDesc W, int64_t i
             stats->chunks++;
         }
     }
-    if (pl.two_lanes) {
-        HIP_CHECK(hipEventRecord(d->ev_join, d->lane[1].stream));
-        HIP_CHECK(hipStreamWaitEvent(d->lane[0].stream, d->ev_join, 0));
-    }
+    if (pl.two_lanes) join_lanes(d, 2);
     if (stats) stats->bootstraps += items;
 }
 
@@ -1477,10 +1496,18 @@ void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32*
 // allocation (each one is a device-wide synchronisation).  eval_circuit_device calls it; a caller that times its first
 // evaluation calls it beforehand (ieache_prepare_batch).
 // Whether an evaluation of `c` over `batch` expressions runs as two expression-half pipelines (Impl::pipe_min).
-static bool pipelined(const Evaluator::Impl* d, const Circuit& c, size_t batch) {
-    if (!d->overlap || !d->use_w64 || batch < 2 || c.n_levels() < 1) return false;
+// -> 0 (no) or the number of pipelines (each gets at least one expression)
+static int pipelined(const Evaluator::Impl* d, const Circuit& c, size_t batch) {
+    if (!d->overlap || !d->use_w64 || batch < 2 || c.n_levels() < 1) return 0;
     const int64_t gates = (int64_t)c.level_offset[c.n_levels()] - (int64_t)c.level_offset[0];
-    return gates * (int64_t)batch >= d->pipe_min * (int64_t)c.n_levels();
+    if (gates * (int64_t)batch < d->pipe_min * (int64_t)c.n_levels()) return 0;
+    return (int)std::min<size_t>((size_t)d->pipe_lanes, batch);
+}
+// expressions [first, first + count) of pipeline k of `lanes`: contiguous, sizes differing by at most one, the first ones longer
+static void pipe_slice(size_t batch, int lanes, int k, size_t* first, size_t* count) {
+    const size_t base = batch / (size_t)lanes, extra = batch % (size_t)lanes;
+    *first = (size_t)k * base + std::min<size_t>((size_t)k, extra);
+    *count = base + ((size_t)k < extra ? 1 : 0);
 }
 
 void Evaluator::prepare_circuit(const Circuit& c, size_t batch) {
@@ -1515,14 +1542,16 @@ void Evaluator::prepare_circuit(const Circuit& c, size_t batch) {
     std::vector<int64_t> level_items;
     for (int32_t L = 1; L <= c.n_levels(); L++)
         level_items.push_back((int64_t)(c.level_offset[L] - c.level_offset[L - 1]) * (int64_t)batch);
-    if (pipelined(d_, c, batch)) {
-        // two pipelines of batch / 2 expressions each (the first takes the odd one)
+    if (const int lanes = pipelined(d_, c, batch)) {
+        // pipelines of batch / lanes expressions each (the first ones take the odd ones)
         int64_t widest = 1;
         for (int32_t L = 1; L <= c.n_levels(); L++) widest = std::max<int64_t>(widest, c.level_offset[L] - c.level_offset[L - 1]);
-        ensure_second_lane(d_);
-        const size_t b0 = (batch + 1) / 2, b1 = batch - b0;
-        reserve_lane(p_, d_, d_->lane[0], std::min<size_t>(d_->chunk, (size_t)widest * b0));
-        reserve_lane(p_, d_, d_->lane[1], std::min<size_t>(d_->chunk, (size_t)widest * b1));
+        ensure_lanes(d_, lanes);
+        for (int k = 0; k < lanes; k++) {
+            size_t first = 0, count = 0;
+            pipe_slice(batch, lanes, k, &first, &count);
+            reserve_lane(p_, d_, d_->lane[k], std::min<size_t>(d_->chunk, (size_t)widest * count));
+        }
     } else {
         reserve_scratch(p_, d_, level_items.data(), level_items.size());
     }
@@ -1546,15 +1575,13 @@ void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const T
     // inputs -> slots 0..n_inputs-1 of every expression
     HIP_CHECK(hipMemcpy2DAsync(d_->store, (size_t)c.n_slots * row_bytes, d_in, (size_t)c.n_inputs * row_bytes,
                                (size_t)c.n_inputs * row_bytes, batch, hipMemcpyDeviceToDevice, stream_));
-    const bool pipes = pipelined(d_, c, batch);
+    const int pipes = pipelined(d_, c, batch);
     if (pipes) {
-        // fork: the second pipeline starts when the inputs are in the wire store
-        HIP_CHECK(hipEventRecord(d_->ev_fork, d_->lane[0].stream));
-        HIP_CHECK(hipStreamWaitEvent(d_->lane[1].stream, d_->ev_fork, 0));
-        d_->concurrency = 2;
+        // fork: the other pipelines start when the inputs are in the wire store
+        fork_lanes(d_, pipes);
+        d_->concurrency = pipes;
         d_->pipelined_evals++;
     }
-    const int64_t half0 = pipes ? (int64_t)((batch + 1) / 2) : (int64_t)batch;
     try {
         for (int32_t L = 1; L <= c.n_levels(); L++) {
             WorkDesc W{};
@@ -1567,10 +1594,13 @@ void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const T
             if (!pipes) {
                 run_items(p_, d_, W, (int64_t)W.ng * (int64_t)batch, tbr, tks, stats);
             } else {
-                // items are expression-major (item = expression x ng + gate): [0, ng x half0) is the first half of the batch
-                run_items(p_, d_, W, (int64_t)W.ng * half0, tbr, tks, stats, 0);
-                W.item0 = (int64_t)W.ng * half0;
-                run_items(p_, d_, W, (int64_t)W.ng * ((int64_t)batch - half0), tbr, tks, stats, 1);
+                // items are expression-major (item = expression x ng + gate): a contiguous range of expressions is a contiguous range of items
+                for (int k = 0; k < pipes; k++) {
+                    size_t first = 0, count = 0;
+                    pipe_slice(batch, pipes, k, &first, &count);
+                    W.item0 = (int64_t)W.ng * (int64_t)first;
+                    run_items(p_, d_, W, (int64_t)W.ng * (int64_t)count, tbr, tks, stats, k);
+                }
             }
             if (stats) stats->levels++;
         }
@@ -1580,8 +1610,7 @@ void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const T
     }
     if (pipes) {
         d_->concurrency = 1;
-        HIP_CHECK(hipEventRecord(d_->ev_join, d_->lane[1].stream));
-        HIP_CHECK(hipStreamWaitEvent(d_->lane[0].stream, d_->ev_join, 0));
+        join_lanes(d_, pipes);
     }
     const int32_t n_out = (int32_t)c.outputs.size();
     hipLaunchKernelGGL(k_gather_outputs, dim3((unsigned)(batch * n_out)), dim3(128), 0, stream_, d_->d_outs, n_out,

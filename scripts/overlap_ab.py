@@ -23,9 +23,10 @@ ctx.set_option("exact_fft", exact)
 NEVER = 1 << 50
 
 
-def set_mode(m):
+def set_mode(m):   # pipes / pipes3 / pipes4: two, three or four pipelines
     ctx.set_option("overlap", 0 if m == "one" else 1)
-    ctx.set_option("pipe_min", NEVER if m == "halves" else 0 if m == "pipes" else NEVER)
+    ctx.set_option("pipe_min", 0 if m.startswith("pipes") else NEVER)
+    ctx.set_option("pipe_lanes", int(m[5:] or 2) if m.startswith("pipes") else 2)
 
 
 for wl, batch, passes in specs:
@@ -45,6 +46,7 @@ for wl, batch, passes in specs:
             ctx.eval_batch_device(kind, bits, batch, d_in.data_ptr(), d_out.data_ptr())
             torch.cuda.synchronize()
             times[m].append(time.perf_counter() - t0)
+            print("[%s x %d pass %d mode %s: %.2f s]" % (wl, batch, r, m, times[m][-1]), file=sys.stderr, flush=True)  # a long run must not look hung
             if r == 0:
                 outs[m] = d_out.clone()
     same = all(bool(torch.equal(outs[modes[0]], outs[m])) for m in modes)

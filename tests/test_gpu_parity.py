@@ -964,6 +964,13 @@ def test_level_overlap_on_two_streams_same_bits(ia, gpu_ctx):
             assert ctx.get_option("pipelined_evals") == before + 1 and ctx.get_option("overlapped_levels") == lv
             assert st.levels == 48 and st.bootstraps == 80 * nb and st.chunks >= 96
         ctx.set_chunk(65536)
+        for lanes, nb in ((3, 40), (4, 39), (4, 3)):       # more pipelines ("pipe_lanes"): ragged slices; never more than expressions
+            ctx.set_option("pipe_lanes", lanes)
+            st = ia.Stats()
+            assert np.array_equal(ctx.eval_batch(1, 16, inp[:nb], st), cref[:nb]), (lanes, nb)
+            assert st.chunks == 48 * min(lanes, nb) and st.bootstraps == 80 * nb
+        ctx.set_option("pipe_lanes", 2)
+        assert not ctx.set_option_ok("pipe_lanes", 5) and not ctx.set_option_ok("pipe_lanes", 1)
         before = ctx.get_option("pipelined_evals")
         assert np.array_equal(ctx.eval_batch(1, 16, inp[:1]), cref[:1]) and ctx.get_option("pipelined_evals") == before  # one expression: one stream
         ctx.set_option("exact_fft", 1)
