@@ -413,6 +413,11 @@ def timed(torch, dist, world, dev, backend, fn):
 T_START = time.perf_counter()
 
 
+def stream_counters(ctx):
+    """(circuit evaluations run as pipelines, levels issued as halves) so far: a leg used two streams when either moved during it"""
+    return ctx.get_option("pipelined_evals"), ctx.get_option("overlapped_levels")
+
+
 def elapsed_all_ranks(torch, dist, dev, backend):
     """seconds since the start of the run, MAX over ranks: what time-box decisions are taken on, so that every rank takes the same one"""
     so_far = time.perf_counter() - T_START
@@ -627,7 +632,6 @@ def main():
         legs = [l for l in args.legs.split(",") if l and l != "none"]
     leg_batch = {"mul32": args.mul32_batch, "muladd64": args.muladd64_batch, "mul128": args.mul128_batch}
     leg_out = {}
-    streams = 2 if overlap_on else 1
     for key, wl, _, full_batch in DEFAULT_LEGS:
         if key not in legs:
             continue
@@ -643,6 +647,7 @@ def main():
             continue
         linfo, linb, ld_in, ld_out = make_inputs(ia, tools, torch, ctx, p, lwe_key, lkind, lbits, lb, rank, dev, 5000 + 1000 * len(leg_out))
         ctx.prepare(lkind, lbits, lb)  # untimed: circuit built and levelised, wire store and the widest level's scratch allocated
+        sc0 = stream_counters(ctx)
         lst = ia.Stats()
         # the leg BASELINE.json quotes its metric on is timed more than once (each pass bracketed on its own), so the line carries
         # a spread; a further pass is dropped, by all ranks together, when the time box has no room for it
@@ -671,8 +676,9 @@ def main():
                          "the primary leg" % l_elapsed,
                # two streams: a launch shares the chip with the other stream's launch of the same level; the evaluator picks kernels
                # by the gate instances in flight on both, and blind_rotate_ms is the time with a rotation in flight on either
-               "streams": streams,
-               "roofline": roofline(p, lst, l_rate / world, pmc, ctx.kernel_for_launch(round(streams * lst.bootstraps / max(1, lst.chunks))))}
+               "streams": 2 if stream_counters(ctx) != sc0 else 1,
+               "roofline": roofline(p, lst, l_rate / world, pmc,
+                                    ctx.kernel_for_launch(round((2 if stream_counters(ctx) != sc0 else 1) * lst.bootstraps / max(1, lst.chunks))))}
         if lb != full_batch:
             rec["sub_batch_of"] = full_batch
             rec["full_share_estimate_s"] = l_elapsed * full_batch / lb
