@@ -514,10 +514,11 @@ __global__ void k_gather_outputs(const OutRef* outs, int32_t n_out, const Torus3
 }  // namespace
 
 // ------------------------------------------------------------------------
-// One stream's worth of per-launch scratch.  Lane 0 runs on the evaluator's own stream and is all a call uses unless a level
-// is overlapped (option "overlap"): then the level's gate instances are cut into pieces that alternate between lane 0 and
-// lane 1 -- a second stream of the SAME context (one copy of the key) with its own extracted-sample rows, blind-rotation
-// state, key-switch digits and audit scratch -- and lane 0 waits for lane 1 before the next level starts.
+// One stream's worth of per-launch scratch.  Lane 0 runs on the evaluator's own stream and is all a call uses with
+// "overlap" = 0.  Otherwise further lanes -- more streams of the SAME context (one copy of the key), each with its own
+// extracted-sample rows, blind-rotation state, key-switch digits and audit scratch -- take either a contiguous share of a
+// batch's expressions through every level of a circuit (pipelines: one fork, one join per evaluation) or every other piece
+// of a wide level (lane 0 then waits for lane 1 before the next level starts).  See Evaluator::set_option in evaluator.h.
 constexpr int kMaxLanes = 4;
 struct Lane {
     hipStream_t stream = nullptr;
