@@ -26,9 +26,22 @@ size_t state_bytes_per_item(const Params& p);
 // Returns the number of k_blind_rotate_w2 launches issued.
 // d_bkf1 / guard: the one-limb spectrum and the two-word guard record of k_blind_rotate_w1 (may be null for the
 // two-limb variants).
+// Rotation of roles for mid-size launches (blind_rotate_w64.hip: launch_mixed_phases): k <= 4 subsets of the items on k streams
+// (streams[0] = the launch's own), tw of them at a time on the two-waves-per-gate kernel for s2 steps while the others take s1
+// (<= 64 x any) steps on the one-wave-per-gate kernel; `cycles` rounds of k phases, the rest of the rotation by the ordinary
+// slice loop.  ev: k events (no timing).  sync: a barrier across the streams at every phase boundary.
+struct MixPlan {
+    int k = 0, tw = 0;
+    int32_t s1 = 0, s2 = 0, cycles = 0;
+    int32_t tail_s1 = 0, tail_s2 = 0;  // a last, shortened round (0 = none)
+    int wg = 4;  // gate instances per workgroup of the one-wave kernel's launches (LDS: with two two-wave gates per CU, 4 or 2 x 2 fit)
+    bool sync = true;
+    hipStream_t streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
 int launch(const Params& p, const dev::DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard,
            const dev::WorkDesc& W, int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice,
-           int32_t variant, const double2* d_twiddles, hipStream_t stream, int wg_gates = 0);
+           int32_t variant, const double2* d_twiddles, hipStream_t stream, int wg_gates = 0, const MixPlan* mix = nullptr);
 // wg_gates: gate instances per workgroup of the two one-wave-per-gate kernels (k_blind_rotate_w1b, guard on one coefficient
 // in four, and k_blind_rotate_x1): 1 .. 4, 0 = 4.  Four gates share a workgroup only for the twiddle table; fewer per
 // workgroup let a launch that does not fill the chip spread evenly over the CUs (LDS: 4 -> 2 workgroups per CU, 3 -> 2, 2 -> 3, 1 -> 6).

@@ -28,8 +28,10 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <stdexcept>
 #include <type_traits>
+#include <vector>
 
 #include "fft512.h"
 
@@ -1500,9 +1502,70 @@ int32_t default_slice() {
     return s > 0 ? (s < 64 ? s : 64) : 16;  // <= 64: one rotation amount per lane
 }
 
+// A mid-size launch (more gates than fit two waves each, fewer than fill the chip with one wave each) as a ROTATION OF ROLES:
+// the items are cut into plan.k contiguous subsets, each driven by its own stream; in phase t the subsets t .. t + tw - 1
+// (mod k) advance s2 CMux steps on the two-waves-per-gate kernel while the others advance s1 steps on the one-wave-per-gate
+// kernel, so that all eight wave slots of every CU work (a gate is one sequential chain of steps: with one wave per gate
+// 1 536 gates can keep only 1 536 of the chip's 2 048 slots busy).  After `cycles` rounds of k phases every subset has done
+// cycles x (tw s2 + (k - tw) s1) steps; the caller's ordinary slice loop finishes the rotation from there on the main stream.
+// Same kernels, same arithmetic per step: bit-identical to any other schedule.  Returns the kernel launches issued.
+static int launch_mixed_phases(const Params& p, const DevKeys& K, const double2* d_bkf1, unsigned* guard, int64_t items,
+                               int32_t* st_acc, uint16_t* st_bara, int32_t nb, const double2* d_twiddles, const MixPlan& plan,
+                               int32_t* steps_done) {
+    int launches = 0;
+    const int k = plan.k, tw = plan.tw;
+    // contiguous subsets of whole workgroups of the one-wave kernel (4 gates) -- and of 3, the other workgroup size
+    const int64_t per = ((items + k - 1) / k + 11) / 12 * 12;
+    std::vector<int32_t> pos(k, 0);
+    hipStream_t main = plan.streams[0];
+    (void)hipEventRecord(plan.ev[0], main);  // the prologue is on the main stream
+    for (int j = 1; j < k; j++) (void)hipStreamWaitEvent(plan.streams[j], plan.ev[0], 0);
+    const int32_t rounds = plan.cycles + ((plan.tail_s1 > 0 && plan.tail_s2 > 0) ? 1 : 0);
+    int32_t total = 0;
+    for (int32_t c = 0; c < rounds; c++) {
+        // the last round may be a shortened one (tail_s1 / tail_s2) that takes the rotation close to its end
+        const int32_t s1c = c < plan.cycles ? plan.s1 : plan.tail_s1, s2c = c < plan.cycles ? plan.s2 : plan.tail_s2;
+        total += tw * s2c + (k - tw) * s1c;
+        for (int t = 0; t < k; t++) {
+            for (int j = 0; j < k; j++) {
+                const int64_t off = (int64_t)j * per, m = std::min<int64_t>(per, items - off);
+                if (m <= 0) continue;
+                const bool two = ((j - t) % k + k) % k < tw;
+                int32_t todo = two ? s2c : s1c;
+                while (todo > 0) {  // the one-wave kernel takes at most 64 steps per launch (one rotation amount per lane)
+                    const int32_t s = two ? todo : std::min<int32_t>(todo, 64);
+                    const int v = two ? kVariantOneLimbTwoWaves : kVariantOneLimbDefault;
+                    if (p.l == 3)
+                        launch_slice<3, 7>(v, m, plan.streams[j], K, nullptr, d_bkf1, st_bara + (size_t)off * nb, nb, st_acc + (size_t)off * 2 * kN,
+                                           pos[j], pos[j] + s, nullptr, guard, d_twiddles, plan.wg);
+                    else
+                        launch_slice<2, 10>(v, m, plan.streams[j], K, nullptr, d_bkf1, st_bara + (size_t)off * nb, nb, st_acc + (size_t)off * 2 * kN,
+                                            pos[j], pos[j] + s, nullptr, guard, d_twiddles, plan.wg);
+                    pos[j] += s;
+                    todo -= s;
+                    launches++;
+                }
+            }
+            if (plan.sync && !(c == rounds - 1 && t == k - 1)) {
+                // phase boundary: nobody starts the next phase before everybody has finished this one (the roles change)
+                for (int j = 0; j < k; j++) (void)hipEventRecord(plan.ev[j], plan.streams[j]);
+                for (int j = 0; j < k; j++)
+                    for (int q = 0; q < k; q++)
+                        if (q != j) (void)hipStreamWaitEvent(plan.streams[j], plan.ev[q], 0);
+            }
+        }
+    }
+    for (int j = 1; j < k; j++) {  // join: the main stream finishes the rotation
+        (void)hipEventRecord(plan.ev[j], plan.streams[j]);
+        (void)hipStreamWaitEvent(main, plan.ev[j], 0);
+    }
+    *steps_done = total;
+    return launches;
+}
+
 int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double2* d_bkf1, unsigned* guard, const WorkDesc& W,
            int64_t items, void* state, Torus32* ext, int32_t steps, Torus32* dbg_acc, int32_t slice, int32_t variant,
-           const double2* d_twiddles, hipStream_t stream, int wg_gates) {
+           const double2* d_twiddles, hipStream_t stream, int wg_gates, const MixPlan* mix) {
     if (!variant_known(variant)) throw std::invalid_argument("unknown blind-rotation variant");
     if (variant_one_limb(variant) && (!d_bkf1 || !guard)) throw std::runtime_error("one-limb blind rotation without its spectrum / guard word");
     int launches = 0;
@@ -1520,7 +1583,14 @@ int launch(const Params& p, const DevKeys& K, const double2* d_bkf, const double
         else
             launch_slice<2, 10>(v, items, stream, K, d_bkf, d_bkf1, st_bara, nb, st_acc, i0, i1, e, guard, d_twiddles, wg_gates);
     };
-    for (int32_t i0 = 0; i0 < nsteps; i0 += S) {
+    int32_t first = 0;
+    if (mix && mix->k >= 2 && mix->cycles >= 1 && variant_one_limb(variant) && mix->streams[0] == stream) {
+        const int32_t cyc = mix->tw * mix->s2 + (mix->k - mix->tw) * mix->s1;
+        const int32_t tail = (mix->tail_s1 > 0 && mix->tail_s2 > 0) ? mix->tw * mix->tail_s2 + (mix->k - mix->tw) * mix->tail_s1 : 0;
+        if (mix->tw >= 1 && mix->tw < mix->k && mix->k <= 4 && mix->s1 >= 1 && mix->s2 >= 1 && mix->cycles * cyc + tail < nsteps)
+            launches += launch_mixed_phases(p, K, d_bkf1, guard, items, st_acc, st_bara, nb, d_twiddles, *mix, &first);
+    }
+    for (int32_t i0 = first; i0 < nsteps; i0 += S) {
         const int32_t i1 = i0 + S < nsteps ? i0 + S : nsteps;
         launches++;
         one(variant, i0, i1, (i1 == nsteps) ? ext : nullptr);  // the last slice extracts instead of storing the accumulator

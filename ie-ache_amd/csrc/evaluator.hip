@@ -28,7 +28,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <map>
 #include <stdexcept>
+#include <tuple>
 #include <vector>
 
 namespace ieache {
@@ -550,6 +553,17 @@ struct Evaluator::Impl {
     int32_t pipe_lanes = 2;      // pipelines a qualifying evaluation is cut into (2 .. kMaxLanes; "pipe_lanes", IEACHE_PIPE_LANES)
     int32_t concurrency = 1;     // streams issuing launches side by side right now (kernel choice is by cnt x concurrency)
     int64_t pipelined_evals = 0;
+    // "pipe_auto" (default 1): with a mean level between pipe_min / 8 and pipe_min neither stream mode wins everywhere
+    // (mul32 x 40: pipelines +5.6 %, muladd64 x 16: -9.7 %, profiles/r5_pipes_vs_mix.txt), so the first four evaluations of a
+    // (circuit, batch) there alternate -- without pipelines, with, without, with -- and later ones take whichever mode had the
+    // faster evaluation.  Every one of them is a complete evaluation with the same output bits; only the schedule differs.
+    int32_t pipe_auto = 1;
+    struct Tuned {
+        double ms[2] = {-1.0, -1.0};  // best wall time of an evaluation without / with pipelines
+        int n[2] = {0, 0};            // trials so far (two each, alternating: a first call also pays for allocations)
+    };
+    std::map<std::tuple<size_t, int32_t, size_t, size_t, bool>, Tuned> tuned;  // (gates, levels, outputs, batch, exact_fft)
+    int64_t tuned_evals = 0;
     // device rows the host-buffer entry points stage their operands and results in: kept between calls, grown on demand
     Torus32* stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
@@ -607,6 +621,13 @@ struct Evaluator::Impl {
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
     int32_t br_variant = w64::default_variant();
     // gate instances per workgroup of the one-wave-per-gate kernels (k_blind_rotate_w1b / _x1): 1 .. 4, 0 = by launch size
+    // mid-size launches (between four and 6.4 gates per CU, one stream): rotation of roles between the two-waves- and the
+    // one-wave-per-gate kernel on up to four streams (w64::MixPlan); "br_mix" 0/1, "mix_s1" steps of a one-wave turn,
+    // "mix_ratio" = 100 x (two-wave steps per one-wave step), "mix_sync" phase barriers
+    int32_t br_mix = 1, mix_s1 = 16, mix_ratio = 200, mix_sync = 0, mix_wg = 2, mix_k = 0, mix_tw = 0;
+    int64_t mixed_launches = 0;
+    bool level_on_two_lanes = false;  // set while a level's halves are being queued on two streams (no rotation of roles then)
+    hipEvent_t ev_mix[kMaxLanes] = {};
     int32_t wg_gates = 0;
     int64_t wg3_max = 0;          // set in init(): launches of up to this many gate instances (6 per CU) take three per workgroup
     // launches of at most this many gate instances (one per CU) use the 2L-waves-per-gate kernel in a
@@ -643,6 +664,7 @@ void Evaluator::init() {
         if (const char* e = getenv("IEACHE_PIPE_MIN")) d_->pipe_min = atoll(e);
         if (const char* e = getenv("IEACHE_PIPE_LANES")) d_->pipe_lanes = atoi(e) >= 2 && atoi(e) <= kMaxLanes ? atoi(e) : 2;
         d_->wg3_max = 6 * (int64_t)cus;
+        if (const char* e = getenv("IEACHE_BR_MIX")) d_->br_mix = atoi(e) != 0;
         if (const char* e = getenv("IEACHE_WG_GATES")) d_->wg_gates = atoi(e) >= 0 && atoi(e) <= 4 ? atoi(e) : 0;
         if (const char* e = getenv("IEACHE_WG3_MAX")) d_->wg3_max = atoll(e);
         if (const char* e = getenv("IEACHE_OVERLAP")) d_->overlap = atoi(e) != 0;
@@ -747,6 +769,8 @@ void Evaluator::destroy() {
     (void)hipFree(d_->ext_mux);
     for (Torus32* st : d_->stage) (void)hipFree(st);
     if (d_->ev_fork) (void)hipEventDestroy(d_->ev_fork);
+    for (int k = 0; k < kMaxLanes; k++)
+        if (d_->ev_mix[k]) (void)hipEventDestroy(d_->ev_mix[k]);
     for (int k = 1; k < kMaxLanes; k++) {
         if (d_->ev_join[k]) (void)hipEventDestroy(d_->ev_join[k]);
         if (d_->lane[k].stream) (void)hipStreamDestroy(d_->lane[k].stream);
@@ -817,6 +841,20 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->ks_mfma_split = (int32_t)value;
     } else if (name == "ks_split_max" && value >= 1 && value <= 64) {
         d_->ks_split_max = (int32_t)value;
+    } else if (name == "br_mix" && (value == 0 || value == 1)) {
+        d_->br_mix = (int32_t)value;
+    } else if (name == "mix_s1" && value >= 1 && value <= 630) {
+        d_->mix_s1 = (int32_t)value;
+    } else if (name == "mix_ratio" && value >= 100 && value <= 400) {
+        d_->mix_ratio = (int32_t)value;
+    } else if (name == "mix_k" && value >= 0 && value <= kMaxLanes && value != 1) {
+        d_->mix_k = (int32_t)value;
+    } else if (name == "mix_tw" && value >= 0 && value < kMaxLanes) {
+        d_->mix_tw = (int32_t)value;
+    } else if (name == "mix_wg" && value >= 1 && value <= 4) {
+        d_->mix_wg = (int32_t)value;
+    } else if (name == "mix_sync" && (value == 0 || value == 1)) {
+        d_->mix_sync = (int32_t)value;
     } else if (name == "wg_gates" && value >= 0 && value <= 4) {
         d_->wg_gates = (int32_t)value;
     } else if (name == "wg3_max" && value >= 0) {
@@ -827,6 +865,9 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->overlap_min = value;
     } else if (name == "pipe_min" && value >= 0) {
         d_->pipe_min = value;
+    } else if (name == "pipe_auto" && (value == 0 || value == 1)) {
+        d_->pipe_auto = (int32_t)value;
+        d_->tuned.clear();
     } else if (name == "pipe_lanes" && value >= 2 && value <= kMaxLanes) {
         d_->pipe_lanes = (int32_t)value;
     } else if (name == "br_wide_max" && value >= 0) {
@@ -869,7 +910,17 @@ bool Evaluator::get_option(const std::string& name, int64_t* value) const {
     else if (name == "overlapped_levels") v = d_->overlapped_levels;  // levels issued on two streams so far (a counter)
     else if (name == "pipe_min") v = d_->pipe_min;
     else if (name == "pipe_lanes") v = d_->pipe_lanes;
+    else if (name == "pipe_auto") v = d_->pipe_auto;
+    else if (name == "tuned_evals") v = d_->tuned_evals;  // evaluations that were one of the two timed trials of a (circuit, batch)
     else if (name == "pipelined_evals") v = d_->pipelined_evals;      // circuit evaluations run as two expression-half pipelines so far
+    else if (name == "br_mix") v = d_->br_mix;
+    else if (name == "mix_s1") v = d_->mix_s1;
+    else if (name == "mix_ratio") v = d_->mix_ratio;
+    else if (name == "mix_sync") v = d_->mix_sync;
+    else if (name == "mix_wg") v = d_->mix_wg;
+    else if (name == "mix_k") v = d_->mix_k;
+    else if (name == "mix_tw") v = d_->mix_tw;
+    else if (name == "mixed_launches") v = d_->mixed_launches;  // (level, piece) launches run as a rotation of roles so far
     else if (name == "wg_gates") v = d_->wg_gates;
     else if (name == "wg3_max") v = d_->wg3_max;
     else if (name == "staging_allocations") v = d_->stage_allocs;  // (re)allocations of the host entry points' staging rows so far
@@ -1050,13 +1101,21 @@ static int pick_wg_gates(const Evaluator::Impl* d, int64_t cnt) {
     return cnt * d->concurrency <= d->wg3_max ? 3 : 4;
 }
 
+static bool mix_geometry(const Evaluator::Impl* d, int64_t cnt, int32_t variant, int* k_out, int* tw_out);
+
 std::string Evaluator::kernel_for_launch(int64_t gates) const {
     if (!d_->use_w64) return "k_blind_rotate_generic";
     int32_t variant, slice;
     pick_br_variant(p_, d_, gates < 1 ? 1 : gates, &variant, &slice);
-    char tag[48];
+    char tag[96];
     snprintf(tag, sizeof tag, "<%d,%d>", (int)p_.l, (int)p_.Bgbit);
     std::string name;
+    int mk = 0, mtw = 0;
+    if (mix_geometry(d_, gates < 1 ? 1 : gates, variant, &mk, &mtw)) {
+        // a rotation of roles between the two kernels (w64::MixPlan): mtw of mk subsets on two waves at a time
+        snprintf(tag, sizeof tag, "<%d,%d> %d of %d subsets on two waves", (int)p_.l, (int)p_.Bgbit, mtw, mk);
+        return std::string("k_blind_rotate_w2r+w1b") + tag;
+    }
     switch (variant) {
         case w64::kVariantOneLimbDefault: name = "k_blind_rotate_w1b"; break;
         case w64::kVariantOneLimbTwoWaves: name = "k_blind_rotate_w2r"; break;
@@ -1077,6 +1136,67 @@ static size_t grown(size_t have, size_t need, size_t cap) {
     return std::max(need, std::min(std::max(cap, need), std::max<size_t>(2 * have, 4096)));
 }
 
+// Whether a launch of `cnt` gate instances runs as a rotation of roles (w64::MixPlan), and with which geometry.  Only where it
+// can pay: the kernels chosen by launch size (br_variant 0) on the one-limb spectrum, the launch alone on the chip (no other
+// stream of this context at work), a whole rotation, and a size between "every gate on two waves" (4 per CU) and 6 per CU
+// (beyond, a third of the gates on two waves at a time would oversubscribe the CUs' eight wave slots).
+// Of k <= 3 subsets tw are on two waves at a time; slots in use = cnt (k + tw) / k <= 8 per CU: the largest tw / k that fits.
+static void ensure_lanes(Evaluator::Impl* d, int lanes);
+// -> false, or the geometry (k subsets, tw of them on two waves at a time) a launch of cnt gate instances takes
+static bool mix_geometry(const Evaluator::Impl* d, int64_t cnt, int32_t variant, int* k_out, int* tw_out) {
+    if (!d->br_mix || d->br_variant != 0 || d->concurrency != 1 || d->level_on_two_lanes || d->exact_fft || d->exact_once) return false;
+    if (!d->use_w64 || !w64::variant_one_limb(variant)) return false;
+    const int64_t cus = d->cus, slots = 8 * cus;
+    // <= 4 per CU: two waves each; > 6.75 per CU: one wave each (measured: +7 % at 6.25 per CU, +3 % at 6.6, nothing at 7)
+    if (cnt <= 4 * cus || (d->mix_k == 0 && cnt * 4 > cus * 27)) return false;
+    // (k, tw) by falling tw / k: the largest share of two-wave gates whose waves fit the slots; a third on two waves is
+    // taken up to 6.75 gates per CU although it oversubscribes the slots by up to an eighth there.
+    // Four subsets (four streams) measured far slower than the plain kernels (profiles/r5_mix_sweep.txt)
+    int k = d->mix_k, tw = d->mix_tw;  // "mix_k" / "mix_tw": a forced geometry (measurement aid), 0 = by launch size
+    if (k == 0) {
+        if (cnt * 5 <= slots * 3) k = 3, tw = 2;
+        else if (cnt * 3 <= slots * 2) k = 2, tw = 1;
+        else k = 3, tw = 1;
+    } else if (tw < 1 || tw >= k) {
+        return false;
+    }
+    *k_out = k;
+    *tw_out = tw;
+    return true;
+}
+static bool plan_mix(const Params& p, Evaluator::Impl* d, Lane& ln, int64_t cnt, int32_t variant, int32_t steps, w64::MixPlan* mix) {
+    int k = 0, tw = 0;
+    if (steps >= 0 || &ln != &d->lane[0] || !mix_geometry(d, cnt, variant, &k, &tw)) return false;
+    const int32_t s1 = d->mix_s1, s2 = (int32_t)((int64_t)s1 * d->mix_ratio / 100);
+    const int32_t cyc = tw * s2 + (k - tw) * s1;
+    const int32_t cycles = (p.n - 1) / cyc;  // at least one step is left for the ordinary loop, which extracts
+    if (cycles < 1) return false;
+    ensure_lanes(d, k);
+    for (int j = 0; j < k; j++)
+        if (!d->ev_mix[j]) HIP_CHECK(hipEventCreateWithFlags(&d->ev_mix[j], hipEventDisableTiming));
+    mix->k = k;
+    mix->tw = tw;
+    mix->s1 = s1;
+    mix->s2 = s2;
+    mix->cycles = cycles;
+    {   // what the whole rounds leave is taken by one more round with both turn lengths scaled down, as long as a one-wave
+        // turn still is a few steps; at least one step stays for the ordinary loop (it extracts)
+        const int32_t rem = p.n - 1 - cycles * cyc;
+        const int32_t t1 = (int32_t)((int64_t)s1 * rem / cyc), t2 = (int32_t)((int64_t)s2 * rem / cyc);
+        if (t1 >= 4 && t2 >= 4 && tw * t2 + (k - tw) * t1 <= rem) {
+            mix->tail_s1 = t1;
+            mix->tail_s2 = t2;
+        }
+    }
+    mix->sync = d->mix_sync != 0;
+    mix->wg = d->mix_wg;
+    for (int j = 0; j < k; j++) {
+        mix->streams[j] = d->lane[j].stream;
+        mix->ev[j] = d->ev_mix[j];
+    }
+    return true;
+}
+
 // Runs `items` gate instances described by W (item0 is advanced per chunk).
 static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, Lane& ln, const WorkDesc& w, int64_t cnt,
                                 Torus32* ext, int32_t steps, Torus32* dbg_acc) {
@@ -1092,8 +1212,11 @@ static int launch_blind_rotate(const Params& p, Evaluator::Impl* d, Lane& ln, co
         }
         int32_t variant, slice;
         pick_br_variant(p, d, cnt, &variant, &slice);
+        w64::MixPlan mix;
+        const bool mixed = plan_mix(p, d, ln, cnt, variant, steps, &mix);
+        if (mixed) d->mixed_launches++;
         return w64::launch(p, d->K, d->bkf_w64, d->bkf1_w64, d->fft_guard, w, cnt, ln.br_state, ext, steps, dbg_acc, slice, variant,
-                           d->tw_w64, stream, pick_wg_gates(d, cnt));
+                           d->tw_w64, stream, pick_wg_gates(d, cnt), mixed ? &mix : nullptr);
     }
     else
         hipLaunchKernelGGL(k_blind_rotate_generic, dim3((unsigned)cnt), dim3(kThreads), d->br_lds, stream, d->K, w, ext,
@@ -1280,6 +1403,7 @@ static void run_items(const Params& p, Evaluator::Impl* d, WorkDesc W, int64_t i
         fork_lanes(d, 2);
         d->overlapped_levels++;
     }
+    d->level_on_two_lanes = pl.two_lanes;
     int k = 0;
     for (int64_t done = 0; done < items; done += pl.piece, k++) {
         const int64_t cnt = std::min<int64_t>(pl.piece, items - done);
@@ -1301,6 +1425,7 @@ static void run_items(const Params& p, Evaluator::Impl* d, WorkDesc W, int64_t i
             stats->chunks++;
         }
     }
+    d->level_on_two_lanes = false;
     if (pl.two_lanes) join_lanes(d, 2);
     if (stats) stats->bootstraps += items;
 }
@@ -1498,11 +1623,37 @@ void Evaluator::mux_device_once(size_t count, const Torus32* d_a, const Torus32*
 // evaluation calls it beforehand (ieache_prepare_batch).
 // Whether an evaluation of `c` over `batch` expressions runs as two expression-half pipelines (Impl::pipe_min).
 // -> 0 (no) or the number of pipelines (each gets at least one expression)
-static int pipelined(const Evaluator::Impl* d, const Circuit& c, size_t batch) {
+// trial (may be null): set to 0 / 1 when this evaluation is one of the two timed trials of its (circuit, batch) -- without /
+// with pipelines -- and to -1 otherwise; the caller then reports the evaluation's wall time to tune_report().
+using TuneKey = std::tuple<size_t, int32_t, size_t, size_t, bool>;
+static TuneKey tune_key(const Evaluator::Impl* d, const Circuit& c, size_t batch) {
+    return std::make_tuple(c.gates.size(), (int32_t)c.n_levels(), c.outputs.size(), batch, d->exact_fft || d->exact_once);
+}
+static int pipelined(Evaluator::Impl* d, const Circuit& c, size_t batch, int* trial = nullptr, bool either = false) {
+    if (trial) *trial = -1;
     if (!d->overlap || !d->use_w64 || batch < 2 || c.n_levels() < 1) return 0;
+    const int lanes = (int)std::min<size_t>((size_t)d->pipe_lanes, batch);
     const int64_t gates = (int64_t)c.level_offset[c.n_levels()] - (int64_t)c.level_offset[0];
-    if (gates * (int64_t)batch < d->pipe_min * (int64_t)c.n_levels()) return 0;
-    return (int)std::min<size_t>((size_t)d->pipe_lanes, batch);
+    const int64_t work = gates * (int64_t)batch, bar = d->pipe_min * (int64_t)c.n_levels();  // mean level against pipe_min
+    if (work >= bar) return lanes;  // from pipe_min on pipelines won every measurement
+    if (d->pipe_auto && d->pipe_min > 0 && work * 8 >= bar) {
+        if (either) return lanes;  // scratch for both modes
+        const auto it = d->tuned.find(tune_key(d, c, batch));
+        const Evaluator::Impl::Tuned t = it == d->tuned.end() ? Evaluator::Impl::Tuned{} : it->second;
+        const bool trying = t.n[0] < 2 || t.n[1] < 2;
+        const int mode = trying ? (t.n[0] <= t.n[1] ? 0 : 1) : (t.ms[1] < t.ms[0] ? 1 : 0);
+        if (trial && trying) *trial = mode;
+        return mode ? lanes : 0;
+    }
+    return 0;
+}
+static void tune_report(Evaluator::Impl* d, const Circuit& c, size_t batch, int trial, double ms) {
+    if (trial < 0 || trial > 1) return;
+    if (d->tuned.size() > 256) d->tuned.clear();  // a daemon sees many batch sizes; the table is a cache, not a record
+    Evaluator::Impl::Tuned& t = d->tuned[tune_key(d, c, batch)];
+    t.ms[trial] = t.n[trial] == 0 ? ms : std::min(t.ms[trial], ms);
+    t.n[trial]++;
+    d->tuned_evals++;
 }
 // expressions [first, first + count) of pipeline k of `lanes`: contiguous, sizes differing by at most one, the first ones longer
 static void pipe_slice(size_t batch, int lanes, int k, size_t* first, size_t* count) {
@@ -1543,8 +1694,10 @@ void Evaluator::prepare_circuit(const Circuit& c, size_t batch) {
     std::vector<int64_t> level_items;
     for (int32_t L = 1; L <= c.n_levels(); L++)
         level_items.push_back((int64_t)(c.level_offset[L] - c.level_offset[L - 1]) * (int64_t)batch);
-    if (const int lanes = pipelined(d_, c, batch)) {
-        // pipelines of batch / lanes expressions each (the first ones take the odd ones)
+    if (const int lanes = pipelined(d_, c, batch, nullptr, /*either=*/true)) {
+        // pipelines of batch / lanes expressions each (the first ones take the odd ones); where the mode is still being
+        // tried out (pipe_auto) the one-stream scratch is reserved as well
+        if (!pipelined(d_, c, batch)) reserve_scratch(p_, d_, level_items.data(), level_items.size());
         int64_t widest = 1;
         for (int32_t L = 1; L <= c.n_levels(); L++) widest = std::max<int64_t>(widest, c.level_offset[L] - c.level_offset[L - 1]);
         ensure_lanes(d_, lanes);
@@ -1576,7 +1729,9 @@ void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const T
     // inputs -> slots 0..n_inputs-1 of every expression
     HIP_CHECK(hipMemcpy2DAsync(d_->store, (size_t)c.n_slots * row_bytes, d_in, (size_t)c.n_inputs * row_bytes,
                                (size_t)c.n_inputs * row_bytes, batch, hipMemcpyDeviceToDevice, stream_));
-    const int pipes = pipelined(d_, c, batch);
+    int trial = -1;
+    const int pipes = pipelined(d_, c, batch, &trial);
+    const auto wall0 = std::chrono::steady_clock::now();
     if (pipes) {
         // fork: the other pipelines start when the inputs are in the wire store
         fork_lanes(d_, pipes);
@@ -1619,6 +1774,7 @@ void Evaluator::eval_circuit_device_once(const Circuit& c, size_t batch, const T
     HIP_CHECK(hipGetLastError());
     tall.mark();
     HIP_CHECK(hipStreamSynchronize(stream_));
+    tune_report(d_, c, batch, trial, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
     if (stats) {
         stats->total_ms += tall.sum_ms();
         stats->blind_rotate_ms += tbr.sum_ms();

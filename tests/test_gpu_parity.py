@@ -971,6 +971,23 @@ def test_level_overlap_on_two_streams_same_bits(ia, gpu_ctx):
             assert st.chunks == 48 * min(lanes, nb) and st.bootstraps == 80 * nb
         ctx.set_option("pipe_lanes", 2)
         assert not ctx.set_option_ok("pipe_lanes", 5) and not ctx.set_option_ok("pipe_lanes", 1)
+        # "pipe_auto": a mean level between pipe_min / 8 and pipe_min (here 3 200 gate instances over 48 levels against pipe_min 300)
+        # is tried both ways -- evaluations 1 and 3 without pipelines, 2 and 4 with -- and then stays with the faster mode;
+        # every one of them gives the same bits
+        ctx.set_option("pipe_min", 300)
+        ctx.set_option("pipe_auto", 1)  # (re)starts the trials
+        p0, t0 = ctx.get_option("pipelined_evals"), ctx.get_option("tuned_evals")
+        seen = []
+        for i in range(6):
+            before = ctx.get_option("pipelined_evals")
+            assert np.array_equal(ctx.eval_batch(1, 16, inp), cref), i
+            seen.append(ctx.get_option("pipelined_evals") - before)
+        assert seen[:4] == [0, 1, 0, 1] and seen[4] == seen[5] and ctx.get_option("tuned_evals") == t0 + 4, seen
+        ctx.set_option("pipe_auto", 0)  # off: below pipe_min there are no pipelines
+        before = ctx.get_option("pipelined_evals")
+        assert np.array_equal(ctx.eval_batch(1, 16, inp), cref) and ctx.get_option("pipelined_evals") == before
+        ctx.set_option("pipe_auto", 1)
+        ctx.set_option("pipe_min", 1)
         before = ctx.get_option("pipelined_evals")
         assert np.array_equal(ctx.eval_batch(1, 16, inp[:1]), cref[:1]) and ctx.get_option("pipelined_evals") == before  # one expression: one stream
         ctx.set_option("exact_fft", 1)
@@ -1168,8 +1185,10 @@ def test_full_size_random_gates_bit_exact_soak(ia, gpu_ctx):
     dev, reruns = ctx.fft_guard()
     assert 0 < dev < 1 / 32 and reruns == reruns0
     ctx.set_option("exact_fft", 0)
-    ctx.set_option("one_limb_min", 257)
-    ctx.set_option("br_wide_max", 256)
+    cus = ctx.get_option("cus")
+    ctx.set_option("one_limb_min", cus + 1)
+    ctx.set_option("br_wide_max", cus)
+    ctx.set_option("two_wave_max", 5 * cus)
 
 
 def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
@@ -1223,6 +1242,33 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
     # level against the oracle's 640 and, beyond them, against the 16 384-gate launch above; ragged last workgroups (1 400 = 3 x 466 + 2)
     cus = ctx.get_option("cus")
     assert ctx.get_option("wg_gates") == 0 and ctx.get_option("wg3_max") == 6 * cus
+    # Mid-size launches (4 .. 6.75 gates per CU) run as a ROTATION OF ROLES by default ("br_mix"): the gates in two or three
+    # subsets on as many streams, some on two waves per gate while the others take one, roles rotating, no kernel of its own --
+    # k_blind_rotate_w2r and k_blind_rotate_w1b on sub-ranges of steps.  Every geometry the launch size selects (2 of 3 / 1 of 2
+    # / 1 of 3 subsets on two waves), ragged subsets, turn lengths that do and do not divide the rotation, against the oracle's
+    # 640 gates and the 16 384-gate launch above; and the same sizes with the rotation switched off.
+    assert ctx.get_option("br_mix") == 1
+    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (4 * cus, 4 * cus + 1, 27 * cus // 4, 27 * cus // 4 + 1)] == \
+        ["k_blind_rotate_w2r", "k_blind_rotate_w2r+w1b", "k_blind_rotate_w2r+w1b", "k_blind_rotate_w1b"]
+    for c, geometry in ((1100, "2 of 3"), (1301, "1 of 2"), (1400, "1 of 3"), (1536, "1 of 3"), (1700, "1 of 3")):
+        assert geometry in ctx.kernel_for_launch(c), (c, ctx.kernel_for_launch(c))
+        before = ctx.get_option("mixed_launches")
+        st = ia.Stats()
+        o = ctx.gates(ia.GATE_XOR, a[:c], b[:c], st)
+        assert ctx.get_option("mixed_launches") == before + 1 and st.blind_rotate_launches > 20 and st.chunks == 1
+        assert np.array_equal(o[:640], ref) and np.array_equal(o, results[1][0][:c]), c
+    for s1, ratio, wg in ((7, 150, 4), (64, 400, 3), (630, 100, 1)):  # (630: no whole round fits -- the plain kernels take the launch)
+        ctx.set_option("mix_s1", s1)
+        ctx.set_option("mix_ratio", ratio)
+        ctx.set_option("mix_wg", wg)
+        assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:1301], b[:1301]), results[1][0][:1301]), (s1, ratio, wg)
+    ctx.set_option("mix_s1", 16)
+    ctx.set_option("mix_ratio", 200)
+    ctx.set_option("mix_wg", 2)
+    ctx.set_option("br_mix", 0)
+    assert ctx.kernel_for_launch(1400).split("<")[0] == "k_blind_rotate_w1b" and ctx.kernel_for_launch(1100).split("<")[0] == "k_blind_rotate_w2r"
+    before = ctx.get_option("mixed_launches")
+    assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:1100], b[:1100]), results[1][0][:1100]) and ctx.get_option("mixed_launches") == before
     for exact in (0, 1):
         ctx.set_option("exact_fft", exact)
         ctx.set_option("two_wave_max", 0)                  # one wave per gate at this size (the default below 5 per CU is two)
@@ -1234,6 +1280,7 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
         ctx.set_option("wg_gates", 0)
         ctx.set_option("two_wave_max", 5 * cus)
     ctx.set_option("exact_fft", 0)
+    ctx.set_option("br_mix", 1)
     with pytest.raises(ia.IeacheError):
         ctx.set_option("wg_gates", 5)
 
