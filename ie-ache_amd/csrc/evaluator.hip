@@ -1144,7 +1144,7 @@ static size_t grown(size_t have, size_t need, size_t cap) {
 static void ensure_lanes(Evaluator::Impl* d, int lanes);
 // -> false, or the geometry (k subsets, tw of them on two waves at a time) a launch of cnt gate instances takes
 static bool mix_geometry(const Evaluator::Impl* d, int64_t cnt, int32_t variant, int* k_out, int* tw_out) {
-    if (!d->br_mix || d->br_variant != 0 || d->concurrency != 1 || d->level_on_two_lanes || d->exact_fft || d->exact_once) return false;
+    if (!d->overlap || !d->br_mix || d->br_variant != 0 || d->concurrency != 1 || d->level_on_two_lanes || d->exact_fft || d->exact_once) return false;
     if (!d->use_w64 || !w64::variant_one_limb(variant)) return false;
     const int64_t cus = d->cus, slots = 8 * cus;
     // <= 4 per CU: two waves each; > 6.75 per CU: one wave each (measured: +7 % at 6.25 per CU, +3 % at 6.6, nothing at 7)
