@@ -1138,7 +1138,7 @@ static size_t grown(size_t have, size_t need, size_t cap) {
 
 // Whether a launch of `cnt` gate instances runs as a rotation of roles (w64::MixPlan), and with which geometry.  Only where it
 // can pay: the kernels chosen by launch size (br_variant 0) on the one-limb spectrum, the launch alone on the chip (no other
-// stream of this context at work), a whole rotation, and a size between "every gate on two waves" (4 per CU) and 6 per CU
+// stream of this context at work), a whole rotation, and a size between "every gate on two waves" (4 per CU) and 6.5 per CU
 // (beyond, a third of the gates on two waves at a time would oversubscribe the CUs' eight wave slots).
 // Of k <= 3 subsets tw are on two waves at a time; slots in use = cnt (k + tw) / k <= 8 per CU: the largest tw / k that fits.
 static void ensure_lanes(Evaluator::Impl* d, int lanes);
@@ -1147,10 +1147,10 @@ static bool mix_geometry(const Evaluator::Impl* d, int64_t cnt, int32_t variant,
     if (!d->overlap || !d->br_mix || d->br_variant != 0 || d->concurrency != 1 || d->level_on_two_lanes || d->exact_fft || d->exact_once) return false;
     if (!d->use_w64 || !w64::variant_one_limb(variant)) return false;
     const int64_t cus = d->cus, slots = 8 * cus;
-    // <= 4 per CU: two waves each; > 6.75 per CU: one wave each (measured: +7 % at 6.25 per CU, +3 % at 6.6, nothing at 7)
-    if (cnt <= 4 * cus || (d->mix_k == 0 && cnt * 4 > cus * 27)) return false;
+    // <= 4 per CU: two waves each; > 6.5 per CU: one wave each (measured: +7 % at 6.25 per CU, +3 .. -7 % at 6.6, nothing at 7)
+    if (cnt <= 4 * cus || (d->mix_k == 0 && cnt * 2 > cus * 13)) return false;
     // (k, tw) by falling tw / k: the largest share of two-wave gates whose waves fit the slots; a third on two waves is
-    // taken up to 6.75 gates per CU although it oversubscribes the slots by up to an eighth there.
+    // taken up to 6.5 gates per CU although it oversubscribes the slots by up to a twelfth there.
     // Four subsets (four streams) measured far slower than the plain kernels (profiles/r5_mix_sweep.txt)
     int k = d->mix_k, tw = d->mix_tw;  // "mix_k" / "mix_tw": a forced geometry (measurement aid), 0 = by launch size
     if (k == 0) {
