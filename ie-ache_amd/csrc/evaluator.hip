@@ -867,7 +867,6 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
         d_->pipe_min = value;
     } else if (name == "pipe_auto" && (value == 0 || value == 1)) {
         d_->pipe_auto = (int32_t)value;
-        d_->tuned.clear();
     } else if (name == "pipe_lanes" && value >= 2 && value <= kMaxLanes) {
         d_->pipe_lanes = (int32_t)value;
     } else if (name == "br_wide_max" && value >= 0) {
@@ -900,6 +899,7 @@ bool Evaluator::set_option(const std::string& name, int64_t value) {
     } else {
         return false;
     }
+    d_->tuned.clear();  // whatever was timed was timed under the old options
     return true;
 }
 
