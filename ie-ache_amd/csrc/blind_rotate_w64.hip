@@ -1514,12 +1514,15 @@ static int launch_mixed_phases(const Params& p, const DevKeys& K, const double2*
                                int32_t* steps_done) {
     int launches = 0;
     const int k = plan.k, tw = plan.tw;
+    auto ok = [](hipError_t e) {  // a failed record / wait would leave the streams unordered: stop here rather than compute on stale state
+        if (e != hipSuccess) throw std::runtime_error(std::string("rotation of roles: ") + hipGetErrorString(e));
+    };
     // contiguous subsets of whole workgroups of the one-wave kernel (4 gates) -- and of 3, the other workgroup size
     const int64_t per = ((items + k - 1) / k + 11) / 12 * 12;
     std::vector<int32_t> pos(k, 0);
     hipStream_t main = plan.streams[0];
-    (void)hipEventRecord(plan.ev[0], main);  // the prologue is on the main stream
-    for (int j = 1; j < k; j++) (void)hipStreamWaitEvent(plan.streams[j], plan.ev[0], 0);
+    ok(hipEventRecord(plan.ev[0], main));  // the prologue is on the main stream
+    for (int j = 1; j < k; j++) ok(hipStreamWaitEvent(plan.streams[j], plan.ev[0], 0));
     const int32_t rounds = plan.cycles + ((plan.tail_s1 > 0 && plan.tail_s2 > 0) ? 1 : 0);
     int32_t total = 0;
     for (int32_t c = 0; c < rounds; c++) {
@@ -1548,16 +1551,16 @@ static int launch_mixed_phases(const Params& p, const DevKeys& K, const double2*
             }
             if (plan.sync && !(c == rounds - 1 && t == k - 1)) {
                 // phase boundary: nobody starts the next phase before everybody has finished this one (the roles change)
-                for (int j = 0; j < k; j++) (void)hipEventRecord(plan.ev[j], plan.streams[j]);
+                for (int j = 0; j < k; j++) ok(hipEventRecord(plan.ev[j], plan.streams[j]));
                 for (int j = 0; j < k; j++)
                     for (int q = 0; q < k; q++)
-                        if (q != j) (void)hipStreamWaitEvent(plan.streams[j], plan.ev[q], 0);
+                        if (q != j) ok(hipStreamWaitEvent(plan.streams[j], plan.ev[q], 0));
             }
         }
     }
     for (int j = 1; j < k; j++) {  // join: the main stream finishes the rotation
-        (void)hipEventRecord(plan.ev[j], plan.streams[j]);
-        (void)hipStreamWaitEvent(main, plan.ev[j], 0);
+        ok(hipEventRecord(plan.ev[j], plan.streams[j]));
+        ok(hipStreamWaitEvent(main, plan.ev[j], 0));
     }
     *steps_done = total;
     return launches;
