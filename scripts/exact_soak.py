@@ -39,5 +39,5 @@ for it in range(passes):
     words += outs[0].size
     dev, reruns = ctx.fft_guard()
     print("pass %d: outputs identical word for word: %s (%d x %d samples of %d words); so far %d bootstraps per mode, %d output words compared, "
-          "guard maximum %.6f, repeats %d; pipelined evaluations so far %d" % (it, same, outs[0].shape[0], outs[0].shape[1], outs[0].shape[2] if outs[0].ndim == 3 else 1, total, words, dev, reruns, ctx.get_option("pipelined_evals")), flush=True)
+          "guard maximum %.6f, repeats %d; pipelined evaluations so far %d, launches run as a rotation of roles %d" % (it, same, outs[0].shape[0], outs[0].shape[1], outs[0].shape[2] if outs[0].ndim == 3 else 1, total, words, dev, reruns, ctx.get_option("pipelined_evals"), ctx.get_option("mixed_launches")), flush=True)
     assert same
