@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "fft512.h"
+#include "mix_plan.h"
 
 namespace ieache {
 namespace w64 {
@@ -1518,7 +1519,7 @@ static int launch_mixed_phases(const Params& p, const DevKeys& K, const double2*
         if (e != hipSuccess) throw std::runtime_error(std::string("rotation of roles: ") + hipGetErrorString(e));
     };
     // contiguous subsets of whole workgroups of the one-wave kernel (4 gates) -- and of 3, the other workgroup size
-    const int64_t per = ((items + k - 1) / k + 11) / 12 * 12;
+    const int64_t per = mix_subset_size(items, k);
     std::vector<int32_t> pos(k, 0);
     hipStream_t main = plan.streams[0];
     ok(hipEventRecord(plan.ev[0], main));  // the prologue is on the main stream

@@ -18,6 +18,7 @@
 #include "codec.h"
 #include "daemon.h"
 #include "evaluator.h"
+#include "mix_plan.h"
 #include "tfhe_host.h"
 
 using namespace ieache;
@@ -796,6 +797,17 @@ int ieache_verif(const char* secret_key_path, const char* nbit_key_path, const c
 int64_t ieache_serve(const char* socket_path, const char* cloud_key_path, const char* nbit_key_path, int device,
                      int64_t max_requests) {
     return ieache_serve_devices(socket_path, cloud_key_path, nbit_key_path, &device, 1, max_requests);
+}
+
+int ieache_debug_mix_plan(int cus, int n, int64_t gates, int s1, int ratio_x100, int out[9]) {
+    if (!out) return fail(IEACHE_EINVAL, "null argument");
+    MixGeometry g;
+    MixSteps m;
+    for (int i = 0; i < 9; i++) out[i] = 0;
+    if (!mix_geometry_for(cus, gates, 0, 0, &g) || !mix_steps_for(n, g, s1, ratio_x100, &m)) return 0;  // no rotation at this size
+    const int v[9] = {g.k, g.tw, m.s1, m.s2, m.cycles, m.tail_s1, m.tail_s2, m.covered, (int)mix_subset_size(gates, g.k)};
+    for (int i = 0; i < 9; i++) out[i] = v[i];
+    return 1;
 }
 
 int ieache_shard_slice(size_t total, size_t parts, size_t part, size_t* first, size_t* count) {

@@ -23,6 +23,7 @@
 #include "keyswitch_mfma.h"
 #include "keyswitch_sliced.h"
 #include "device_common.h"
+#include "mix_plan.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1146,51 +1147,30 @@ static void ensure_lanes(Evaluator::Impl* d, int lanes);
 static bool mix_geometry(const Evaluator::Impl* d, int64_t cnt, int32_t variant, int* k_out, int* tw_out) {
     if (!d->overlap || !d->br_mix || d->br_variant != 0 || d->concurrency != 1 || d->level_on_two_lanes || d->exact_fft || d->exact_once) return false;
     if (!d->use_w64 || !w64::variant_one_limb(variant)) return false;
-    const int64_t cus = d->cus, slots = 8 * cus;
-    // <= 4 per CU: two waves each; > 6.5 per CU: one wave each (measured: +7 % at 6.25 per CU, +3 .. -7 % at 6.6, nothing at 7)
-    if (cnt <= 4 * cus || (d->mix_k == 0 && cnt * 2 > cus * 13)) return false;
-    // (k, tw) by falling tw / k: the largest share of two-wave gates whose waves fit the slots; a third on two waves is
-    // taken up to 6.5 gates per CU although it oversubscribes the slots by up to a twelfth there.
-    // Four subsets (four streams) measured far slower than the plain kernels (profiles/r5_mix_sweep.txt)
-    int k = d->mix_k, tw = d->mix_tw;  // "mix_k" / "mix_tw": a forced geometry (measurement aid), 0 = by launch size
-    if (k == 0) {
-        if (cnt * 5 <= slots * 3) k = 3, tw = 2;
-        else if (cnt * 3 <= slots * 2) k = 2, tw = 1;
-        else k = 3, tw = 1;
-    } else if (tw < 1 || tw >= k) {
-        return false;
-    }
-    *k_out = k;
-    *tw_out = tw;
+    MixGeometry g;  // mix_plan.h: "mix_k" / "mix_tw" force a geometry (measurement aid), 0 = by launch size
+    if (!mix_geometry_for(d->cus, cnt, d->mix_k, d->mix_tw, &g) || g.k > kMaxLanes) return false;
+    *k_out = g.k;
+    *tw_out = g.tw;
     return true;
 }
 static bool plan_mix(const Params& p, Evaluator::Impl* d, Lane& ln, int64_t cnt, int32_t variant, int32_t steps, w64::MixPlan* mix) {
-    int k = 0, tw = 0;
-    if (steps >= 0 || &ln != &d->lane[0] || !mix_geometry(d, cnt, variant, &k, &tw)) return false;
-    const int32_t s1 = d->mix_s1, s2 = (int32_t)((int64_t)s1 * d->mix_ratio / 100);
-    const int32_t cyc = tw * s2 + (k - tw) * s1;
-    const int32_t cycles = (p.n - 1) / cyc;  // at least one step is left for the ordinary loop, which extracts
-    if (cycles < 1) return false;
-    ensure_lanes(d, k);
-    for (int j = 0; j < k; j++)
+    MixGeometry g;
+    if (steps >= 0 || &ln != &d->lane[0] || !mix_geometry(d, cnt, variant, &g.k, &g.tw)) return false;
+    MixSteps m;
+    if (!mix_steps_for(p.n, g, d->mix_s1, d->mix_ratio, &m)) return false;
+    ensure_lanes(d, g.k);
+    for (int j = 0; j < g.k; j++)
         if (!d->ev_mix[j]) HIP_CHECK(hipEventCreateWithFlags(&d->ev_mix[j], hipEventDisableTiming));
-    mix->k = k;
-    mix->tw = tw;
-    mix->s1 = s1;
-    mix->s2 = s2;
-    mix->cycles = cycles;
-    {   // what the whole rounds leave is taken by one more round with both turn lengths scaled down, as long as a one-wave
-        // turn still is a few steps; at least one step stays for the ordinary loop (it extracts)
-        const int32_t rem = p.n - 1 - cycles * cyc;
-        const int32_t t1 = (int32_t)((int64_t)s1 * rem / cyc), t2 = (int32_t)((int64_t)s2 * rem / cyc);
-        if (t1 >= 4 && t2 >= 4 && tw * t2 + (k - tw) * t1 <= rem) {
-            mix->tail_s1 = t1;
-            mix->tail_s2 = t2;
-        }
-    }
+    mix->k = g.k;
+    mix->tw = g.tw;
+    mix->s1 = m.s1;
+    mix->s2 = m.s2;
+    mix->cycles = m.cycles;
+    mix->tail_s1 = m.tail_s1;
+    mix->tail_s2 = m.tail_s2;
     mix->sync = d->mix_sync != 0;
     mix->wg = d->mix_wg;
-    for (int j = 0; j < k; j++) {
+    for (int j = 0; j < g.k; j++) {
         mix->streams[j] = d->lane[j].stream;
         mix->ev[j] = d->ev_mix[j];
     }

@@ -163,6 +163,7 @@ def lib():
     L.ieache_serve.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int64]
     L.ieache_serve_devices.restype = C.c_int64
     L.ieache_serve_devices.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int, C.c_int64]
+    L.ieache_debug_mix_plan.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.ieache_shard_slice.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ieache_client_ping.argtypes = [C.c_char_p]
     L.ieache_client_run_dir.argtypes = [C.c_char_p, C.c_char_p]

@@ -258,6 +258,11 @@ int ieache_circuit_simulate_ex(int kind, int bits, int fold_constants, const uin
  * key switch u [count][N+1] -> out [count][n+1] */
 int ieache_debug_blind_rotate(ieache_ctx* ctx, size_t count, const int32_t* x, int32_t* acc, int32_t steps);
 int ieache_debug_keyswitch(ieache_ctx* ctx, size_t count, const int32_t* u, int32_t* out);
+/* The plan of a rotation of roles (option "br_mix") for a launch of `gates` gate instances on a device of `cus` compute units,
+ * rotations of n steps, one-wave turns of s1 steps, two-wave turns of s1 x ratio_x100 / 100: returns 1 and out = {subsets k,
+ * subsets on two waves at a time, s1, s2, whole rounds, shortened round's s1, s2, steps covered by the rounds (< n), gate
+ * instances per subset}, or 0 (out zeroed) when that launch size takes a single kernel.  No device needed (csrc/mix_plan.h). */
+int ieache_debug_mix_plan(int cus, int n, int64_t gates, int s1, int ratio_x100, int out[9]);
 
 /* ------------------------------------------------------------------ *
  * 4. CPU tools around the path (no GPU): what Keygen/keygen.c:22-51,  *
