@@ -730,7 +730,8 @@ def main():
             "streams": 2 if overlap_on else 1,
             "frac_end_to_end": value / world * alg * 1e-12 / FP64_VALU_PEAK_TFLOPS,
             "frac_blind_rotation_in_flight": stats.bootstraps / max(1e-9, stats.blind_rotate_ms * 1e-3) * alg * 1e-12 / FP64_VALU_PEAK_TFLOPS,
-            "blind_rotate_ms_per_step": stats.blind_rotate_ms / args.steps, "launches_per_step": stats.blind_rotate_launches / args.steps}
+            # (ieache_stats describes the LAST call it was passed to: one step)
+            "blind_rotate_ms_last_step": stats.blind_rotate_ms, "launches_last_step": stats.blind_rotate_launches}
         out["config"]["overlap_streams"] = 2 if overlap_on else 1
         out.update(leg_out)
         if exact_out:
