@@ -964,6 +964,14 @@ def test_level_overlap_on_two_streams_same_bits(ia, gpu_ctx):
             assert ctx.get_option("pipelined_evals") == before + 1 and ctx.get_option("overlapped_levels") == lv
             assert st.levels == 48 and st.bootstraps == 80 * nb and st.chunks >= 96
         ctx.set_chunk(65536)
+        # a tripped guard / a differing audited row under pipelines: the call repeats itself on the two-limb kernels (as pipelines too)
+        reruns = ctx.fft_guard()[1]
+        ctx.set_option("fft_guard_inject", 1)
+        assert np.array_equal(ctx.eval_batch(1, 16, inp), cref) and ctx.fft_guard()[1] == reruns + 1
+        ctx.set_option("fft_audit", 1)
+        ctx.set_option("fft_audit_inject", 1)
+        assert np.array_equal(ctx.eval_batch(1, 16, inp), cref) and ctx.fft_guard()[1] == reruns + 2
+        ctx.set_option("fft_audit", 64)
         for lanes, nb in ((3, 40), (4, 39), (4, 3)):       # more pipelines ("pipe_lanes"): ragged slices; never more than expressions
             ctx.set_option("pipe_lanes", lanes)
             st = ia.Stats()
@@ -1265,6 +1273,15 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
     ctx.set_option("mix_s1", 16)
     ctx.set_option("mix_ratio", 200)
     ctx.set_option("mix_wg", 2)
+    # the audit after a rotation of roles (every launch audited here), and a guard trip during one: repeated on the two-limb kernel
+    ctx.set_option("fft_audit", 1)
+    au0, reruns = ctx.fft_audit(), ctx.fft_guard()[1]
+    assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:1301], b[:1301]), results[1][0][:1301])
+    au1 = ctx.fft_audit()
+    assert au1["audits"] == au0["audits"] + 1 and au1["mismatches"] == au0["mismatches"] and ctx.fft_guard()[1] == reruns
+    ctx.set_option("fft_guard_inject", 1)
+    assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:1301], b[:1301]), results[1][0][:1301]) and ctx.fft_guard()[1] == reruns + 1
+    ctx.set_option("fft_audit", 64)
     ctx.set_option("br_mix", 0)
     assert ctx.kernel_for_launch(1400).split("<")[0] == "k_blind_rotate_w1b" and ctx.kernel_for_launch(1100).split("<")[0] == "k_blind_rotate_w2r"
     before = ctx.get_option("mixed_launches")
