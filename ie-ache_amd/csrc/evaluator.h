@@ -121,11 +121,12 @@ public:
     //   * "pipe_auto" (default 1): with a mean level between pipe_min / 8 and pipe_min neither mode wins everywhere, so the
     //     first four evaluations of a (circuit, batch) alternate without / with pipelines and later ones take the faster
     //     (each is a complete evaluation; "tuned_evals" counts the trials);
-    //   * "br_mix" (default 1; IEACHE_BR_MIX): a launch of 4 .. 6.5 gates per CU that has the chip to itself runs as a
-    //     ROTATION OF ROLES -- the gates in two or three subsets on as many streams, one or two subsets at a time on the
-    //     two-waves-per-gate kernel for "mix_s1" x "mix_ratio" / 100 steps while the others take "mix_s1" steps on the
-    //     one-wave-per-gate kernel ("mix_wg" gates per workgroup), roles rotating, so that all eight wave slots of a CU
-    //     work: +6 .. 21 % over the single kernel at 1 025 .. 1 664 gates (profiles/r5_mix_sweep.txt).
+    //   * "br_mix" (default 1; IEACHE_BR_MIX): a launch of 4 .. 7 gates per CU -- or of 8 .. 10.5: a full round of the
+    //     one-wave kernel plus a small remainder -- that has the chip to itself runs as a ROTATION OF ROLES: the gates in
+    //     three subsets on three streams, two subsets at a time on the two-waves-per-gate kernel for "mix_s1" x "mix_ratio"
+    //     / 100 steps while the third takes "mix_s1" steps on the one-wave-per-gate kernel ("mix_wg" gates per workgroup),
+    //     roles rotating, so that every wave slot of a CU works whatever the launch size: a size-independent 180-185 k
+    //     gates/s where the single kernels give 130-180 k (profiles/r5_mix_sweep.txt; csrc/mix_plan.h).
     // The same gate instances go through the same kernels' arithmetic either way: output bits do not depend on it.
     // 0 = every launch on one stream -- the mode per-kernel timings (rocprofv3 averages, bench.py's roofline) are taken
     // in, since overlapped kernels share the chip.

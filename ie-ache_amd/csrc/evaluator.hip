@@ -622,9 +622,9 @@ struct Evaluator::Impl {
     int32_t br_slice = 0;         // CMux steps per blind-rotation launch; 0 = the kernel's default
     int32_t br_variant = w64::default_variant();
     // gate instances per workgroup of the one-wave-per-gate kernels (k_blind_rotate_w1b / _x1): 1 .. 4, 0 = by launch size
-    // mid-size launches (between four and 6.4 gates per CU, one stream): rotation of roles between the two-waves- and the
-    // one-wave-per-gate kernel on up to four streams (w64::MixPlan); "br_mix" 0/1, "mix_s1" steps of a one-wave turn,
-    // "mix_ratio" = 100 x (two-wave steps per one-wave step), "mix_sync" phase barriers
+    // launches of 4 .. 7 and 8 .. 10.5 gates per CU (mix_plan.h): rotation of roles between the two-waves- and the
+    // one-wave-per-gate kernel on three streams (w64::MixPlan); "br_mix" 0/1, "mix_s1" steps of a one-wave turn,
+    // "mix_ratio" = 100 x (two-wave steps per one-wave step), "mix_sync" phase barriers, "mix_k" / "mix_tw" a forced geometry
     int32_t br_mix = 1, mix_s1 = 16, mix_ratio = 200, mix_sync = 0, mix_wg = 2, mix_k = 0, mix_tw = 0;
     int64_t mixed_launches = 0;
     bool level_on_two_lanes = false;  // set while a level's halves are being queued on two streams (no rotation of roles then)
@@ -1139,9 +1139,8 @@ static size_t grown(size_t have, size_t need, size_t cap) {
 
 // Whether a launch of `cnt` gate instances runs as a rotation of roles (w64::MixPlan), and with which geometry.  Only where it
 // can pay: the kernels chosen by launch size (br_variant 0) on the one-limb spectrum, the launch alone on the chip (no other
-// stream of this context at work), a whole rotation, and a size between "every gate on two waves" (4 per CU) and 6.5 per CU
-// (beyond, a third of the gates on two waves at a time would oversubscribe the CUs' eight wave slots).
-// Of k <= 3 subsets tw are on two waves at a time; slots in use = cnt (k + tw) / k <= 8 per CU: the largest tw / k that fits.
+// stream of this context at work), a whole rotation, and a size mix_plan.h names: 4 .. 7 gates per CU, or a full round of the
+// one-wave kernel plus a small remainder (8 .. 10.5 per CU).
 static void ensure_lanes(Evaluator::Impl* d, int lanes);
 // -> false, or the geometry (k subsets, tw of them on two waves at a time) a launch of cnt gate instances takes
 static bool mix_geometry(const Evaluator::Impl* d, int64_t cnt, int32_t variant, int* k_out, int* tw_out) {

@@ -2,7 +2,8 @@
 // launch_mixed_phases), free of any device state so that the CPU tests can check it (ieache_debug_mix_plan).
 //
 // A launch of `gates` gate instances on a device of `cus` compute units (8 wave slots each) is cut into k subsets; tw of them
-// at a time run on the two-waves-per-gate kernel for s2 steps while the others take s1 steps on the one-wave-per-gate kernel.
+// at a time run on the two-waves-per-gate kernel for s2 steps while the others take s1 steps on the one-wave-per-gate kernel
+// (k = 3, tw = 2 unless forced).
 // One round = k phases = tw s2 + (k - tw) s1 steps for every gate.  `cycles` whole rounds, then optionally one shortened
 // round (tail_s1 / tail_s2), then the ordinary slice loop for what is left (at least one step: it extracts).
 #pragma once
@@ -15,18 +16,23 @@ struct MixGeometry {
 };
 
 // -> false when the launch size is not one the rotation is used for.  force_k / force_tw: a forced geometry (0 = by size).
+// By size: three subsets, two of them on two waves at a time, for launches of
+//   * 4 .. 7 gates per CU (1 025 .. 1 792 at 256 CUs): more gates than fit on two waves each, fewer than a full round of
+//     one wave each -- +2 .. 21 % over the single kernel, crossover at 7.1 per CU;
+//   * 8 .. 10.5 gates per CU (2 049 .. 2 688): a full round of the one-wave kernel plus a small remainder that would cost
+//     a second, nearly empty round -- +2 .. 25 %, crossover at 10.7 per CU.
+// The waves of the two-wave subsets oversubscribe the CUs' eight slots there (up to 2.2 x): the hardware queues the
+// workgroups, and the rotation runs at a size-independent 180-185 k gates/s, between the two kernels' own full-chip rates.
+// Measured and dropped (profiles/r5_mix_sweep.txt): one of two / one of three subsets on two waves (the geometries whose
+// waves FIT the slots: 3 .. 8 % slower than two of three at the same size), four subsets (four streams share the runtime's
+// four hardware queues with the context's other streams).
 inline bool mix_geometry_for(int64_t cus, int64_t gates, int force_k, int force_tw, MixGeometry* g) {
-    const int64_t slots = 8 * cus;
-    // <= 4 per CU: every gate fits on two waves; > 6.5 per CU: one wave each (measured: +7 % at 6.25 per CU, +3 .. -7 % at 6.6)
-    if (cus <= 0 || gates <= 4 * cus || (force_k == 0 && gates * 2 > cus * 13)) return false;
+    if (cus <= 0 || gates <= 4 * cus) return false;  // <= 4 per CU: every gate fits on two waves
     int k = force_k, tw = force_tw;
     if (k == 0) {
-        // the largest share of two-wave gates whose waves fit the slots: 2 of 3 subsets, else 1 of 2, else 1 of 3 (which
-        // is taken up to 6.5 gates per CU although it oversubscribes the slots by up to a twelfth there); four subsets --
-        // four streams -- measured far slower than the plain kernels (profiles/r5_mix_sweep.txt)
-        if (gates * 5 <= slots * 3) k = 3, tw = 2;
-        else if (gates * 3 <= slots * 2) k = 2, tw = 1;
-        else k = 3, tw = 1;
+        const bool below_a_round = gates <= 7 * cus, above_a_round = gates > 8 * cus && gates * 2 <= 21 * cus;
+        if (!below_a_round && !above_a_round) return false;
+        k = 3, tw = 2;
     } else if (k < 2 || k > 4 || tw < 1 || tw >= k) {
         return false;
     }

@@ -26,8 +26,8 @@ stats)
   find $OUT/stats_exact -name "*kernel_stats.csv" | head -3 ;;
 sizes)
   IEACHE_OVERLAP=0 timeout -k 10 300 python scripts/br_bench.py 1 37 128 256 300 512 768 1024 1216 1400 1536 1792 2048 4096 8192 16384 > $OUT/kernels_by_launch_size.txt 2>&1
-  echo "# the product's defaults (streams on: rotation of roles at 1 025 .. 1 664 gates, level halves from 4 096):" >> $OUT/kernels_by_launch_size.txt
-  timeout -k 10 300 python scripts/br_bench.py 1024 1100 1216 1280 1365 1400 1536 1600 1700 1792 2048 4096 8192 16384 >> $OUT/kernels_by_launch_size.txt 2>&1
+  echo "# the product's defaults (streams on: rotation of roles at 1 025 .. 1 792 and 2 049 .. 2 688 gates, level halves from 4 096):" >> $OUT/kernels_by_launch_size.txt
+  timeout -k 10 300 python scripts/br_bench.py 1024 1100 1216 1280 1365 1400 1536 1600 1700 1792 1900 2048 2100 2304 2560 2688 2816 3072 4096 8192 16384 >> $OUT/kernels_by_launch_size.txt 2>&1
   tail -32 $OUT/kernels_by_launch_size.txt ;;
 esac
 done

@@ -270,8 +270,9 @@ def test_twisted_radix8_passes_match_their_defining_sums(tmp_path):
 
 def test_rotation_of_roles_plan(ia):
     """csrc/mix_plan.h through ieache_debug_mix_plan: which mid-size launches run as a rotation of roles between the two-waves- and
-    the one-wave-per-gate kernel, with which geometry, and that the rounds never reach the end of the rotation (the ordinary
-    loop needs at least one step: it extracts).  256 CUs = 2 048 wave slots."""
+    the one-wave-per-gate kernel (4 .. 7 gates per CU, and 8 .. 10.5: a full round plus a small remainder), with three subsets of
+    which two are on two waves at a time, and that the rounds never reach the end of the rotation (the ordinary loop needs at
+    least one step: it extracts).  256 CUs."""
     import ctypes as C
     L = ia.lib()
 
@@ -280,21 +281,18 @@ def test_rotation_of_roles_plan(ia):
         used = L.ieache_debug_mix_plan(cus, n, gates, s1, ratio, out)
         return used, list(out)
 
-    assert plan(1024)[0] == 0 and plan(1665)[0] == 0 and plan(16384)[0] == 0 and plan(1)[0] == 0   # single kernels outside 4 .. 6.5 per CU
-    geometry = {}
-    for gates in range(1025, 1665):
+    for gates in (1, 1024, 1793, 2048, 2689, 4096, 16384):  # single kernels outside the two ranges
+        assert plan(gates)[0] == 0, gates
+    for gates in list(range(1025, 1793)) + list(range(2049, 2689)):
         used, (k, tw, s1, s2, cycles, t1, t2, covered, per) = plan(gates)
-        assert used == 1 and (k, tw) in ((3, 2), (2, 1), (3, 1)) and (s1, s2) == (16, 32), gates
-        slots = sum(min(per, max(0, gates - j * per)) * (2 if j < tw else 1) for j in range(k))   # waves in flight in any phase, at most
-        assert slots <= 2048 * 13 / 12 + 24 and (slots <= 2048 + 24 or (k, tw) == (3, 1)), (gates, slots)
+        assert used == 1 and (k, tw) == (3, 2) and (s1, s2) == (16, 32), gates
         assert per % 12 == 0 and per * k >= gates > per * (k - 1)                                   # whole workgroups, no empty subset
         rnd = tw * s2 + (k - tw) * s1
         assert cycles >= 1 and covered == cycles * rnd + (tw * t2 + (k - tw) * t1) and covered < 630
         assert (t1 == 0 and t2 == 0) or (t1 >= 4 and t2 >= 4)
-        assert 630 - covered <= max(rnd, 3 * k + 8), (gates, covered)                                # the ordinary loop is left with little
-        geometry.setdefault((k, tw), []).append(gates)
-    assert geometry[(3, 2)] == list(range(1025, 1229)) and geometry[(2, 1)] == list(range(1229, 1366)) and geometry[(3, 1)][-1] == 1664
+        assert 630 - covered <= 3 * k + 8, (gates, covered)                                          # the ordinary loop is left with little
     # other devices, other rotations: the thresholds are per CU; a rotation too short for one round is left to the single kernels
-    assert plan(4 * 304 + 1, cus=304)[0] == 1 and plan(4 * 304, cus=304)[0] == 0 and plan(1300, n=40)[0] == 0
+    assert plan(4 * 304 + 1, cus=304)[0] == 1 and plan(4 * 304, cus=304)[0] == 0 and plan(7 * 304 + 1, cus=304)[0] == 0
+    assert plan(8 * 304 + 1, cus=304)[0] == 1 and plan(1300, n=40)[0] == 0
     used, out = plan(1300, n=500, s1=64, ratio=188)
-    assert used == 1 and out[:5] == [2, 1, 64, 120, 2] and out[7] < 500
+    assert used == 1 and out[:5] == [3, 2, 64, 120, 1] and out[7] < 500

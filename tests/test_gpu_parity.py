@@ -1250,21 +1250,29 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
     # level against the oracle's 640 and, beyond them, against the 16 384-gate launch above; ragged last workgroups (1 400 = 3 x 466 + 2)
     cus = ctx.get_option("cus")
     assert ctx.get_option("wg_gates") == 0 and ctx.get_option("wg3_max") == 6 * cus
-    # Mid-size launches (4 .. 6.5 gates per CU) run as a ROTATION OF ROLES by default ("br_mix"): the gates in two or three
+    # Launches of 4 .. 7 and of 8 .. 10.5 gates per CU run as a ROTATION OF ROLES by default ("br_mix"): the gates in two or three
     # subsets on as many streams, some on two waves per gate while the others take one, roles rotating, no kernel of its own --
-    # k_blind_rotate_w2r and k_blind_rotate_w1b on sub-ranges of steps.  Every geometry the launch size selects (2 of 3 / 1 of 2
-    # / 1 of 3 subsets on two waves), ragged subsets, turn lengths that do and do not divide the rotation, against the oracle's
+    # k_blind_rotate_w2r and k_blind_rotate_w1b on sub-ranges of steps.  Both size ranges, forced geometries (1 of 2 / 1 of 3
+    # subsets on two waves), ragged subsets, turn lengths that do and do not divide the rotation, against the oracle's
     # 640 gates and the 16 384-gate launch above; and the same sizes with the rotation switched off.
     assert ctx.get_option("br_mix") == 1
-    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (4 * cus, 4 * cus + 1, 13 * cus // 2, 13 * cus // 2 + 1)] == \
-        ["k_blind_rotate_w2r", "k_blind_rotate_w2r+w1b", "k_blind_rotate_w2r+w1b", "k_blind_rotate_w1b"]
-    for c, geometry in ((1100, "2 of 3"), (1301, "1 of 2"), (1400, "1 of 3"), (1536, "1 of 3"), (1660, "1 of 3")):
+    assert [ctx.kernel_for_launch(c).split("<")[0] for c in (4 * cus, 4 * cus + 1, 7 * cus, 7 * cus + 1, 8 * cus, 8 * cus + 1, 21 * cus // 2, 21 * cus // 2 + 1)] == \
+        ["k_blind_rotate_w2r", "k_blind_rotate_w2r+w1b", "k_blind_rotate_w2r+w1b", "k_blind_rotate_w1b", "k_blind_rotate_w1b",
+         "k_blind_rotate_w2r+w1b", "k_blind_rotate_w2r+w1b", "k_blind_rotate_w1b"]
+    for c, geometry in ((1100, "2 of 3"), (1301, "2 of 3"), (1536, "2 of 3"), (1790, "2 of 3"), (2300, "2 of 3"), (2688, "2 of 3")):
         assert geometry in ctx.kernel_for_launch(c), (c, ctx.kernel_for_launch(c))
         before = ctx.get_option("mixed_launches")
         st = ia.Stats()
         o = ctx.gates(ia.GATE_XOR, a[:c], b[:c], st)
         assert ctx.get_option("mixed_launches") == before + 1 and st.blind_rotate_launches > 20 and st.chunks == 1
         assert np.array_equal(o[:640], ref) and np.array_equal(o, results[1][0][:c]), c
+    for fk, ftw in ((2, 1), (3, 1)):                       # forced geometries ("mix_k" / "mix_tw": measurement aids)
+        ctx.set_option("mix_k", fk)
+        ctx.set_option("mix_tw", ftw)
+        assert ("%d of %d" % (ftw, fk)) in ctx.kernel_for_launch(1301)
+        assert np.array_equal(ctx.gates(ia.GATE_XOR, a[:1301], b[:1301]), results[1][0][:1301]), (fk, ftw)
+    ctx.set_option("mix_k", 0)
+    ctx.set_option("mix_tw", 0)
     for s1, ratio, wg in ((7, 150, 4), (64, 400, 3), (630, 100, 1)):  # (630: no whole round fits -- the plain kernels take the launch)
         ctx.set_option("mix_s1", s1)
         ctx.set_option("mix_ratio", ratio)
