@@ -1250,8 +1250,8 @@ def test_one_limb_kernels_match_two_limb_over_many_gates(ia, gpu_ctx):
     # level against the oracle's 640 and, beyond them, against the 16 384-gate launch above; ragged last workgroups (1 400 = 3 x 466 + 2)
     cus = ctx.get_option("cus")
     assert ctx.get_option("wg_gates") == 0 and ctx.get_option("wg3_max") == 6 * cus
-    # Launches of 4 .. 7 and of 8 .. 10.5 gates per CU run as a ROTATION OF ROLES by default ("br_mix"): the gates in two or three
-    # subsets on as many streams, some on two waves per gate while the others take one, roles rotating, no kernel of its own --
+    # Launches of 4 .. 7 and of 8 .. 10.5 gates per CU run as a ROTATION OF ROLES by default ("br_mix"): the gates in three
+    # subsets on three streams, two of them on two waves per gate while the third takes one, roles rotating, no kernel of its own --
     # k_blind_rotate_w2r and k_blind_rotate_w1b on sub-ranges of steps.  Both size ranges, forced geometries (1 of 2 / 1 of 3
     # subsets on two waves), ragged subsets, turn lengths that do and do not divide the rotation, against the oracle's
     # 640 gates and the 16 384-gate launch above; and the same sizes with the rotation switched off.
