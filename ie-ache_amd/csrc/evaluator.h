@@ -118,7 +118,7 @@ public:
     //   * otherwise (flat gate calls, narrower circuits) a level of at least "overlap_min" gate instances (default 16 per
     //     CU; IEACHE_OVERLAP_MIN) is cut into pieces of at most half the level that alternate between the two streams, and
     //     the next level starts when both have finished.
-    //   * "pipe_auto" (default 1): with a mean level between pipe_min / 8 and pipe_min neither mode wins everywhere, so the
+    //   * "pipe_auto" (default 1): with a mean level between pipe_min / 8 and 2 x pipe_min neither mode wins everywhere, so the
     //     first four evaluations of a (circuit, batch) alternate without / with pipelines and later ones take the faster
     //     (each is a complete evaluation; "tuned_evals" counts the trials);
     //   * "br_mix" (default 1; IEACHE_BR_MIX): a launch of 4 .. 7 gates per CU -- or of 8 .. 10.5: a full round of the

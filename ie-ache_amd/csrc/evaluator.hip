@@ -554,7 +554,7 @@ struct Evaluator::Impl {
     int32_t pipe_lanes = 2;      // pipelines a qualifying evaluation is cut into (2 .. kMaxLanes; "pipe_lanes", IEACHE_PIPE_LANES)
     int32_t concurrency = 1;     // streams issuing launches side by side right now (kernel choice is by cnt x concurrency)
     int64_t pipelined_evals = 0;
-    // "pipe_auto" (default 1): with a mean level between pipe_min / 8 and pipe_min neither stream mode wins everywhere
+    // "pipe_auto" (default 1): with a mean level between pipe_min / 8 and 2 x pipe_min neither stream mode wins everywhere
     // (mul32 x 40: pipelines +5.6 %, muladd64 x 16: -9.7 %, profiles/r5_pipes_vs_mix.txt), so the first four evaluations of a
     // (circuit, batch) there alternate -- without pipelines, with, without, with -- and later ones take whichever mode had the
     // faster evaluation.  Every one of them is a complete evaluation with the same output bits; only the schedule differs.
@@ -1614,7 +1614,10 @@ static int pipelined(Evaluator::Impl* d, const Circuit& c, size_t batch, int* tr
     const int lanes = (int)std::min<size_t>((size_t)d->pipe_lanes, batch);
     const int64_t gates = (int64_t)c.level_offset[c.n_levels()] - (int64_t)c.level_offset[0];
     const int64_t work = gates * (int64_t)batch, bar = d->pipe_min * (int64_t)c.n_levels();  // mean level against pipe_min
-    if (work >= bar) return lanes;  // from pipe_min on pipelines won every measurement
+    // From 2 x pipe_min on pipelines won every measurement.  Below, it depends on where the levels fall among the kernels'
+    // regimes (a level of 2 200 gate instances as two pipelines' launches of 1 100 costs a second, nearly empty round; on one
+    // stream it runs as a rotation of roles): tried both ways from pipe_min / 8 up.
+    if (work >= 2 * bar || (!d->pipe_auto && work >= bar)) return lanes;
     if (d->pipe_auto && d->pipe_min > 0 && work * 8 >= bar) {
         if (either) return lanes;  // scratch for both modes
         const auto it = d->tuned.find(tune_key(d, c, batch));

@@ -191,7 +191,7 @@ int ieache_ctx_set_option(ieache_ctx* ctx, const char* name, int64_t value);
  * EXPRESSIONS through every level with no join in between; otherwise a level of at least "overlap_min" gate instances
  * (default 16 per CU) is issued as two halves with a join before the next level.  Same output bits either way; 0 = one
  * stream, the mode per-kernel timings are taken in (csrc/evaluator.h).  "pipe_auto" (0/1, default 1): between pipe_min / 8
- * and pipe_min the mode is chosen per (circuit, batch) by timing its first four evaluations, two in each mode.
+ * and 2 x pipe_min the mode is chosen per (circuit, batch) by timing its first four evaluations, two in each mode.
  * "br_mix" (0/1, default 1; IEACHE_BR_MIX): launches of 4 .. 7 and of 8 .. 10.5 gates per CU run as a rotation of roles
  * between the two-waves- and the one-wave-per-gate kernel on three streams ("mix_s1", "mix_ratio", "mix_wg": turn length,
  * step ratio x 100, gates per workgroup).  "wg_gates" (0 = by launch size, 1 .. 4): gate instances per workgroup of the
