@@ -9,7 +9,7 @@ wl, batch, mode, passes = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.ar
 p = ia.default_params()
 k = tools.keygen_raw(p, (314, 1592, 657))
 ctx = ia.Context.from_arrays(p, k["bk"], k["ksk"])
-ctx.set_option("fft_audit", 0)
+ctx.set_option("fft_audit", int(os.environ.get("AUDIT", "0")))  # AUDIT=K: every K-th one-limb launch audited (the product's default is 64)
 dev = torch.device("cuda", 0)
 kind, bits, _, name = B.WORKLOADS[wl]
 info, inb, d_in, d_out = B.make_inputs(ia, tools, torch, ctx, p, k["lwe_key"], kind, bits, batch, 0, dev, 1000)
